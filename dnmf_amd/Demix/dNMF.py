@@ -1,0 +1,382 @@
+"""Deformable NMF demixing on MI355X: the Python surface of the reference's ``Demix/dNMF.py``
+(``ExponentialFP``, ``DeformableNMF``, ``SimulatedVideoDataset``) on hand-written HIP kernels.
+
+The classes keep the reference's constructor arguments, attributes and method signatures so that its
+``demo.py`` runs against this module unchanged (``from Demix.dNMF import ...`` resolves to this file
+through the ``Demix`` package at the repository root).  What is different is underneath:
+
+* ``ExponentialFP.forward`` (reference ``Demix/dNMF.py:53-62``) calls K1 ``dnmf_warp_gather`` for the
+  materialised ``A_t`` / ``grid`` and the fused path (``dnmf_recon_image`` + K2 ``dnmf_warp_recon_grad``)
+  for ``A_tC``; ``A_tC`` carries an autograd node whose backward is K2 again, so
+  ``F.mse_loss(A_tC, batch).backward()`` deposits ``beta.grad`` like the reference.
+* ``DeformableNMF.update_motion`` (``:181-194``) runs one fused K2 launch per mini-batch and hands
+  ``beta.grad`` to the caller's optimiser; it never materialises the K warped footprints.
+* ``DeformableNMF.update_footprints`` (``:163-179``) computes the per-frame Gram matrices and right-hand
+  sides once with K3 ``dnmf_warp_gram_rhs`` (fp32 MFMA) and iterates the multiplicative update with K4
+  ``dnmf_mu_temporal``; the reference recomputes both contractions in every iteration from a float64
+  ``A_t`` of all frames.
+
+There is no CPU fallback: without ``libdnmf_hip.so`` and a GPU these classes raise.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from .. import ops
+from ..WUtils import Simulator
+
+device = 'cuda'
+
+# update_footprints returns the reference's dense (X,Y,Z,K,T) float64 A_t only below this many bytes
+DENSE_RETURN_LIMIT = 1 << 31
+# update_motion keeps the reconstruction images of all T frames resident below this many bytes
+RECON_CACHE_LIMIT = 64 << 30
+
+
+def _sz_list(sz):
+    return [int(s) for s in (sz.tolist() if isinstance(sz, torch.Tensor) else sz)]
+
+
+class _WarpRecon(torch.autograd.Function):
+    """A_tC = trilinear warp of the reconstruction image S = A.C_t; differentiable w.r.t. beta."""
+
+    @staticmethod
+    def forward(ctx, beta, fp, times, C):
+        times_t = torch.as_tensor(list(times), dtype=torch.int32, device=beta.device)
+        Csel = C.to(device=beta.device, dtype=torch.float32).contiguous()
+        S = ops.recon_image(fp.packed_footprints(), fp.K, Csel, times_t)
+        out = ops.warp_recon_grad(S, None, None, None, fp.sz_list, beta.detach(), times_t, grad=None,
+                                  gout=torch.zeros((len(times_t), fp.P), dtype=torch.float32, device=beta.device),
+                                  want_recon=True, want_loss=False, want_reg=True)
+        ctx.fp, ctx.S, ctx.times_t = fp, S, times_t
+        ctx.save_for_backward(beta)
+        ctx.mark_non_differentiable(out["reg"])
+        return out["recon"].view(len(times_t), *fp.sz_list), out["reg"]
+
+    @staticmethod
+    def backward(ctx, g_recon, _g_reg):
+        (beta,) = ctx.saved_tensors
+        grad = torch.zeros_like(beta)
+        gout = g_recon.contiguous().view(len(ctx.times_t), ctx.fp.P).float()
+        ops.warp_recon_grad(ctx.S, None, None, None, ctx.fp.sz_list, beta.detach(), ctx.times_t, grad=grad, gout=gout,
+                            want_recon=False, want_loss=False, want_reg=False)
+        return grad, None, None, None
+
+
+class ExponentialFP(nn.Module):
+    """Gaussian footprints ``A`` deformed per frame by a quadratic map with coefficients ``beta``.
+
+    Mirrors reference ``Demix/dNMF.py:18-122``: same constructor, same attributes (``beta`` leaf
+    (10,3,T) with requires_grad, ``A`` (X,Y,Z,K), ``sigma``, ``pos``, ``sz``, ``flow_id``,
+    ``transformed``), same ``forward(times, C) -> (A_tC, A_t, grid, reg)``.
+    """
+
+    def __init__(self, sz, K, T, positions=None, shape_std=3):
+        super().__init__()
+        ops._lib.load()  # fail here, loudly, if the HIP library is not built
+        sz_t = torch.as_tensor(sz)
+        self.sz_list = _sz_list(sz_t)
+        X, Y, Z = self.sz_list
+        self.K, self.T, self.P = int(K), int(T), X * Y * Z
+
+        # voxel lattice and its quadratic basis (reference :22-23); kept for attribute compatibility --
+        # the kernels regenerate both from the voxel index
+        gx, gy, gz = torch.meshgrid(torch.arange(X), torch.arange(Y), torch.arange(Z), indexing='ij')
+        flow_id = torch.stack((gx, gy, gz), 3).float().to(device)
+        self.flow_id = flow_id
+        self.transformed = ExponentialFP.quadratic_basis(flow_id)
+
+        beta = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].repeat(1, 1, T)
+        self.beta = beta.to(device).contiguous()
+        self.beta.requires_grad = True
+
+        self.sigma = (torch.ones(K) * shape_std).to(device)
+        if positions is None:
+            self.pos = (1 + torch.rand(K, 3) * sz_t[None, :]).to(device)
+        else:
+            self.pos = positions.to(device)
+        self.sz = sz_t.to(device)
+
+        # A[x,y,z,k] = exp(-sum_d (coord_d - pos[k,d])^2 / sigma_k^2), neuron by neuron to bound the
+        # temporary (the reference builds an (X,Y,Z,3,K) tensor at once, :39-40)
+        A = torch.empty((X, Y, Z, K), dtype=torch.float32, device=device)
+        for k in range(K):
+            A[..., k] = torch.exp((-(flow_id - self.pos[k][None, None, None, :].float()) ** 2
+                                   / self.sigma[k] ** 2).sum(3))
+        self.A = A
+        self._packed = None
+        self._packed_version = None
+
+    @staticmethod
+    def quadratic_basis(P):
+        """[1, x, y, z, x^2, y^2, z^2, xy, xz, yz] (reference :46-51)."""
+        x, y, z = P[..., 0:1], P[..., 1:2], P[..., 2:3]
+        return torch.cat((x * 0 + 1, P, P * P, x * y, x * z, y * z), -1)
+
+    def packed_footprints(self):
+        """(P,Kp) zero-padded copy of ``A`` for the MFMA kernels; rebuilt when ``A`` is replaced or edited."""
+        key = (self.A.data_ptr(), self.A._version)
+        if self._packed is None or self._packed_version != key:
+            self._packed = ops.pack_footprints(self.A.contiguous())
+            self._packed_version = key
+        return self._packed
+
+    def forward(self, times, C):
+        """Returns ``(A_tC (B,X,Y,Z), A_t (B,K,X,Y,Z), grid (X,Y,Z,3,B), reg (B))`` for the frames ``times``."""
+        times = [int(t) for t in (times.tolist() if hasattr(times, 'tolist') else times)]
+        A_tC, reg = _WarpRecon.apply(self.beta, self, times, C)
+        A_t, grid = ops.warp_gather(self.A.contiguous(), self.beta.detach(), times)
+        return A_tC, A_t, grid, reg
+
+    @staticmethod
+    def log_det_jac(B, P):
+        """log|det J| of the quadratic map at ``P`` (reference :107-122, with its 8/9 row convention)."""
+        x, y, z = P[0], P[1], P[2]
+        # column c of the Jacobian as the reference writes it: rows 8 / 9 of beta act as the yz / xz terms
+        col = [(B[1, c] + 2 * B[4, c] * x + B[7, c] * y + B[9, c] * z,
+                B[2, c] + 2 * B[5, c] * y + B[7, c] * x + B[8, c] * z,
+                B[3, c] + 2 * B[6, c] * z + B[8, c] * y + B[9, c] * x) for c in range(3)]
+        (a, b, c), (d, e, f), (g, h, i) = col
+        return torch.log(abs(a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)))
+
+    @staticmethod
+    def spatial_pushforward(dl, batch_size, sz, device, model):
+        """Reference :69-93: ``A_t`` (X,Y,Z,K,T) and the raw video ``Y`` (X,Y,Z,T) as float64 numpy for
+        every frame the loader yields.  ``Y_i`` (nearest-neighbour registration) is not produced by this
+        build yet and is returned as zeros."""
+        X, Y_, Z = _sz_list(sz)
+        K = model.C.shape[0]
+        A_list, Y_list = [], []
+        for data in dl:
+            times = data[1].tolist()
+            A_t, _ = ops.warp_gather(model.fp.A.contiguous(), model.fp.beta.detach(), times, want_grid=False)
+            A_list.append(A_t.permute(2, 3, 4, 1, 0).double().cpu().numpy())
+            Y_list.append(data[0].permute(1, 2, 3, 0).double().cpu().numpy())
+        A_t = np.concatenate(A_list, 4)
+        Yv = np.concatenate(Y_list, 3)
+        return A_t, np.zeros_like(Yv), Yv
+
+
+class DeformableNMF:
+    """Reference ``Demix/dNMF.py:124-194``: owns the spatial model ``fp`` and the traces ``C`` (K,T)."""
+
+    def __init__(self, sz, K, T, positions=None):
+        self.SpatialModel = ExponentialFP
+        self.fp = self.SpatialModel(sz=sz, K=K, T=T, positions=positions)
+        self.C = torch.rand((K, T)).to(device)
+        self.A = torch.rand((K, _sz_list(sz)[0], _sz_list(sz)[1])).to(device)  # unused in the reference too (:131)
+        self.verbose = True
+        if positions is not None:
+            # D = 1 - exp(-0.01 * distance(voxel, centre_k)), float64 (reference :133-137)
+            lat = self.fp.flow_id.reshape(-1, 3).double()
+            d = torch.cdist(lat, positions.to(device).double())
+            X, Y, Z = _sz_list(sz)
+            self.D = (1 - torch.exp(-.01 * d)).reshape(X, Y, Z, K).cpu().numpy()
+        else:
+            self.D = None
+        self._ws_k2 = None
+        self._ws_k3 = None
+
+    # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
+    @staticmethod
+    def update_temporal(A_t, C, Y, gamma=None):
+        """One multiplicative update of ``C`` given explicit warped footprints (reference :139-149).
+        ``A_t`` (X,Y,Z,K,T), ``C`` (K,T), ``Y`` (X,Y,Z,T) numpy; returns float64 numpy (K,T)."""
+        A_t, C, Y = np.asarray(A_t), np.asarray(C), np.asarray(Y)
+        X, Y_, Z, K, T = A_t.shape
+        P = X * Y_ * Z
+        dev = torch.device(device)
+        A_dev = torch.from_numpy(np.ascontiguousarray(np.moveaxis(A_t, 4, 0).reshape(T, P, K))).to(dev, torch.float32)
+        Apk = ops.pack_footprints(A_dev)                                   # (T*P, Kp)
+        frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(Y, 3, 0).reshape(T, P))).to(dev, torch.float32)
+        ident = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].repeat(1, 1, T).to(dev)
+        G, r, _ = ops.warp_gram_rhs(Apk, K, (X, Y_, Z), ident.contiguous(), list(range(T)), frames,
+                                    a_frame_stride=P * Apk.shape[1])
+        return _mu_temporal(G, r, torch.from_numpy(np.asarray(C, dtype=np.float64)).to(dev), gamma, 1).cpu().numpy()
+
+    @staticmethod
+    def update_spatial(A, C, Y_i, D=None, gamma=None):
+        """One multiplicative update of un-warped footprints (reference :151-160).  The reference's driver
+        never calls it (its call site is commented out); evaluated here with torch float64 on the GPU."""
+        dev = torch.device(device)
+        A_, C_, Y_ = (torch.from_numpy(np.asarray(v, dtype=np.float64)).to(dev) for v in (A, C, Y_i))
+        C_s = C_ @ C_.T
+        A1 = torch.einsum('mnt,kt->mnk', Y_, C_)
+        A2 = torch.einsum('mnk,kp->mnp', A_, C_s)
+        if D is not None:
+            A2 = A2 + gamma * torch.from_numpy(np.asarray(D, dtype=np.float64)).to(dev)
+        return (A_ * A1 / (A2 + 1e-32)).cpu().numpy()
+
+    # ---- fit steps -------------------------------------------------------------------------------------
+    def _gather_frames(self, loader):
+        """All frames the loader yields, in its order, resident on the GPU as (T,P) plus their indices."""
+        if isinstance(loader, ResidentLoader):
+            return loader.frames_2d(), loader.order_tensor()
+        fr, idx = [], []
+        for data in loader:
+            fr.append(data[0].to(device, torch.float32).reshape(data[0].shape[0], -1))
+            idx.append(torch.as_tensor(data[1]).to(device, torch.int32).reshape(-1))
+        return torch.cat(fr, 0).contiguous(), torch.cat(idx, 0)
+
+    def update_footprints(self, testloader, batch_size, sz, gamma_c=1e-2, gamma_a=1e0, iter_c=10, return_dense=None):
+        """Reference :163-179: ``iter_c`` multiplicative updates of ``self.C`` under the current warp.
+
+        Returns ``(A_t, Y_i, Y)`` like the reference when the dense float64 ``A_t`` fits
+        ``DENSE_RETURN_LIMIT`` (or ``return_dense=True``); otherwise ``(None, None, None)``."""
+        fp = self.fp
+        K, P = fp.K, fp.P
+        with torch.no_grad():
+            frames, order = self._gather_frames(testloader)
+            T_loc = frames.shape[0]
+            G, r, self._ws_k3 = ops.warp_gram_rhs(fp.packed_footprints(), K, fp.sz_list, fp.beta.detach(), order,
+                                                  frames, workspace=self._ws_k3)
+            Csel = self.C.to(device, torch.float32)[:, order.long()].contiguous()
+            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c)
+            C = self.C.to(device, torch.float32).clone()
+            C[:, order.long()] = Cnew
+            self.C = C
+            if return_dense is None:
+                return_dense = 8 * P * K * T_loc <= DENSE_RETURN_LIMIT
+            if not return_dense:
+                return None, None, None
+            X, Y_, Z = fp.sz_list
+            A_t = np.empty((X, Y_, Z, K, T_loc))
+            step = max(1, int((256 << 20) // (4 * P * K)))
+            for s in range(0, T_loc, step):
+                a, _ = ops.warp_gather(fp.A.contiguous(), fp.beta.detach(), order[s:s + step], want_grid=False)
+                A_t[..., s:s + step] = a.permute(2, 3, 4, 1, 0).double().cpu().numpy()
+            Yv = frames.view(T_loc, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
+            return A_t, np.zeros_like(Yv), Yv
+
+    def _recon_cache(self, frame_ids=None):
+        """Reconstruction images S_t = A.C_t of all T frames (C is constant inside update_motion)."""
+        fp = self.fp
+        lds = (fp.P + 3) // 4 * 4
+        if 4 * lds * fp.T > RECON_CACHE_LIMIT:
+            return None
+        S = torch.empty((fp.T, lds), dtype=torch.float32, device=device)
+        C = self.C.to(device, torch.float32).contiguous()
+        all_t = torch.arange(fp.T, dtype=torch.int32, device=device)
+        for s in range(0, fp.T, 32768):
+            ops.recon_image(fp.packed_footprints(), fp.K, C, all_t[s:s + 32768], out=S[s:s + 32768])
+        return S
+
+    def update_motion(self, dataloader, optimizer, gamma=0, epochs=20):
+        """Reference :181-194: mini-batch steps of the caller's optimiser on ``fp.beta`` against
+        ``mse(A_tC, frames) + gamma*mean(reg)`` (the reg term is gradient-free in the reference, :60-61)."""
+        fp = self.fp
+        beta = fp.beta
+        S_all = self._recon_cache()
+        Cdev = None if S_all is not None else self.C.to(device, torch.float32).contiguous()
+        resident = isinstance(dataloader, ResidentLoader)
+        for epoch in range(1, epochs + 1):
+            if self.verbose:
+                print('Epoch ' + str(epoch))
+            fp.train()
+            for batch_idx, data in enumerate(dataloader.iter_indices() if resident else dataloader):
+                optimizer.zero_grad()
+                times = data if resident else data[1]
+                times = torch.as_tensor(times).to(device, torch.int32).reshape(-1)
+                if beta.grad is None:
+                    beta.grad = torch.zeros_like(beta)
+                if resident:
+                    frames, frame_ids = dataloader.frames_2d(), times
+                else:
+                    frames, frame_ids = data[0].to(device, torch.float32).reshape(times.numel(), -1), None
+                if S_all is not None:
+                    S, s_ids = S_all, times
+                else:
+                    S, s_ids = ops.recon_image(fp.packed_footprints(), fp.K, Cdev, times), None
+                want = self.verbose and batch_idx % 10 == 0
+                out = ops.warp_recon_grad(S, s_ids, frames, frame_ids, fp.sz_list, beta.detach(), times,
+                                          grad=beta.grad, want_loss=want, want_reg=want, workspace=self._ws_k2)
+                self._ws_k2 = out["workspace"]
+                optimizer.step()
+                if want:
+                    print('Recon: ' + str(out["loss"][0]))
+                    print('Reg: ' + str(out["reg"]))
+
+    def fit(self, dataloader, testloader, optimizer, batch_size, outer=5, gamma=1, epochs=10, gamma_c=0, iter_c=50):
+        """Convenience wrapper of the loop ``demo.py:44-46`` writes out (not part of the reference)."""
+        out = (None, None, None)
+        for _ in range(outer):
+            self.update_motion(dataloader, optimizer, gamma=gamma, epochs=epochs)
+            out = self.update_footprints(testloader, batch_size, self.fp.sz_list, gamma_c=gamma_c, iter_c=iter_c)
+        return out
+
+
+def _mu_temporal(G, r, C, gamma, iters):
+    """``iters`` multiplicative updates on (T,K,K) / (T,K) Gram data.
+
+    ``C`` fp32 (K,T): the state update_footprints starts from (the reference's ``self.C``); without the
+    neighbour term the whole loop is one K4 launch (fp64 inside, one rounding to fp32 at the end, as
+    reference :177).  ``C`` fp64, or gamma != 0: the fp64 state is iterated with the one-round kernel.
+    Returns a tensor of C's dtype."""
+    if C.dtype == torch.float32 and (gamma is None or gamma == 0):
+        return ops.mu_temporal(G, r, C.contiguous().clone(), iters)
+    a = C.double().contiguous().clone()
+    b = torch.empty_like(a)
+    for _ in range(iters):
+        ops.mu_temporal_step(G, r, a, b, 0.0 if gamma is None else float(gamma))
+        a, b = b, a
+    return a.to(C.dtype)
+
+
+class ResidentLoader:
+    """Iterates mini-batches of a video that already lives on the GPU as (T,P) rows.
+
+    Yields ``(frames (B,X,Y,Z) view, idx int32 tensor)`` like a DataLoader over SimulatedVideoDataset; the
+    fit steps recognise it and index the resident rows directly instead of copying batches (the timed
+    region of bench.py starts with the inputs in HBM).  ``order`` may be a fixed permutation (list of
+    frame indices) or None for 0..T-1; ``shuffle=True`` draws a new permutation per epoch from
+    ``generator``."""
+
+    def __init__(self, frames, sz, batch_size, shuffle=False, generator=None):
+        self.sz = _sz_list(sz)
+        self._frames = frames.to(device, torch.float32).reshape(frames.shape[0], -1).contiguous()
+        self.batch_size, self.shuffle, self.generator = int(batch_size), shuffle, generator
+        self.T = self._frames.shape[0]
+
+    def frames_2d(self):
+        return self._frames
+
+    def order_tensor(self):
+        return torch.arange(self.T, dtype=torch.int32, device=device)
+
+    def __len__(self):
+        return (self.T + self.batch_size - 1) // self.batch_size
+
+    def iter_indices(self):
+        """Frame indices of each mini-batch (int32 tensors on the GPU), without touching the frames."""
+        perm = torch.randperm(self.T, generator=self.generator) if self.shuffle else torch.arange(self.T)
+        perm = perm.to(device, torch.int32)
+        for s in range(0, self.T, self.batch_size):
+            yield perm[s:s + self.batch_size]
+
+    def __iter__(self):
+        for idx in self.iter_indices():
+            yield self._frames[idx.long()].view(-1, *self.sz), idx
+
+
+class SimulatedVideoDataset(Dataset):
+    """Reference ``Demix/dNMF.py:196-217``: a synthetic video and its ground truth."""
+
+    def __init__(self, K, T, sz, shape_std, density, bg_snr, traces, motion, motion_par):
+        video, positions, traces = Simulator.generate_video(K, T, _sz_list(sz), shape_std, density, bg_snr, traces,
+                                                            motion, motion_par)
+        self.video = video.float()
+        self.positions = positions
+        self.traces = traces
+
+    def __len__(self):
+        return self.video.shape[3]
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        sample = self.video[:, :, :, idx]
+        sample[sample < 0] = 0  # in place on the stored video, like the reference (:214-215)
+        return sample, idx

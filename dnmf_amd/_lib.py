@@ -1,0 +1,64 @@
+"""ctypes binding of libdnmf_hip.so (the C ABI declared in include/dnmf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, the error is raised here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnmf_hip.so")
+ABI_VERSION = 1
+
+_vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
+
+# name -> (restype, argtypes); mirrors include/dnmf_hip.h line by line
+SIGNATURES = {
+    "dnmf_version": (_i, []),
+    "dnmf_last_error": (C.c_char_p, []),
+    "dnmf_padded_k": (_i, [_i]),
+    "dnmf_pack_footprints": (_i, [_vp, _l, _i, _vp, _i, _vp]),
+    "dnmf_warp_gather": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "dnmf_recon_image": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
+    "dnmf_warp_recon_grad_workspace": (_sz, [_l, _i]),
+    "dnmf_warp_recon_grad": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _sz, _vp]),
+    "dnmf_warp_gram_rhs_workspace": (_sz, [_l, _i, _i]),
+    "dnmf_warp_gram_rhs": (_i, [_vp, _i, _i, _l, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz,
+                                _vp]),
+    "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class DnmfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DnmfHipError(
+            f"{LIB_PATH} is missing: build it with `python -m dnmf_amd.build` (hipcc, gfx950). "
+            "dnmf_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = stale library
+        fn.restype, fn.argtypes = res, args
+    if lib.dnmf_version() != ABI_VERSION:
+        raise DnmfHipError(f"{LIB_PATH}: ABI {lib.dnmf_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().dnmf_last_error().decode(errors="replace")
+        kind = "argument error" if rc < 0 else "hipError_t"
+        raise DnmfHipError(f"{what} failed ({kind} {rc}): {msg}")

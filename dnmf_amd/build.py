@@ -1,0 +1,46 @@
+"""Build libdnmf_hip.so (gfx950) in-tree with hipcc.
+
+    python -m dnmf_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library links only against the HIP runtime; torch is not
+involved.  ``-ffp-contract=off``: the coordinate round trip of the warp must not be contracted into FMAs
+(see csrc/common.hpp); the kernels spell out ``fmaf`` where a fused multiply-add is wanted.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdnmf_hip.so")
+SOURCES = ["api_common.hip", "warp_gather.hip", "recon_image.hip", "warp_recon_grad.hip", "warp_gram_rhs.hip",
+           "mu_temporal.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dnmf_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source into ``dnmf_amd/libdnmf_hip.so``; returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print("[dnmf_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,117 @@
+// Shared host/device helpers of libdnmf_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/dnmf_hip.h"
+
+namespace dnmf {
+
+// ---- error plumbing (thread-local text behind dnmf_last_error) ---------------------------------
+char *last_error_buffer();
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+#define DNMF_REQUIRE(cond, code, ...)              \
+    do {                                           \
+        if (!(cond)) return ::dnmf::fail((code), __VA_ARGS__); \
+    } while (0)
+
+// ---- volume geometry -----------------------------------------------------------------------------
+struct Volume {
+    int X, Y, Z;
+    long P;
+    float sx1, sy1, sz1;  // (S-1) as fp32, the divisor of Demix/dNMF.py:55 (sz is int64 there)
+};
+
+inline Volume make_volume(int X, int Y, int Z) {
+    Volume v;
+    v.X = X, v.Y = Y, v.Z = Z;
+    v.P = (long)X * Y * Z;
+    v.sx1 = (float)(X - 1), v.sy1 = (float)(Y - 1), v.sz1 = (float)(Z - 1);
+    return v;
+}
+
+// One warped sample position: integer base corner, the two weights per axis and per-corner validity.
+struct Sample {
+    float ux, uy, uz;     // un-normalised source coordinates (voxel units)
+    int x0, y0, z0;       // floor
+    float wx0, wx1, wy0, wy1, wz0, wz1;  // weight of corner 0 / corner 1 along each axis
+};
+
+// q_d = sum_a basis_a(x,y,z) * beta[a][d]; basis order [1,x,y,z,x^2,y^2,z^2,xy,xz,yz]
+// (Demix/dNMF.py:46-51,54).  `b` points at 30 floats laid out [a*3 + d].
+__device__ __forceinline__ float poly_q(const float *b, int d, float x, float y, float z) {
+    float q = b[0 + d];
+    q = fmaf(b[3 + d], x, q);
+    q = fmaf(b[6 + d], y, q);
+    q = fmaf(b[9 + d], z, q);
+    q = fmaf(b[12 + d], __fmul_rn(x, x), q);
+    q = fmaf(b[15 + d], __fmul_rn(y, y), q);
+    q = fmaf(b[18 + d], __fmul_rn(z, z), q);
+    q = fmaf(b[21 + d], __fmul_rn(x, y), q);
+    q = fmaf(b[24 + d], __fmul_rn(x, z), q);
+    q = fmaf(b[27 + d], __fmul_rn(y, z), q);
+    return q;
+}
+
+// n = 2q/(S-1) - 1 exactly as the reference evaluates it in fp32 (Demix/dNMF.py:55): IEEE multiply,
+// IEEE divide, IEEE subtract, no contraction.
+__device__ __forceinline__ float normalise(float q, float sm1) {
+    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, q), sm1), 1.0f);
+}
+
+// torch grid_sampler_unnormalize, align_corners=True: ((n + 1) / 2) * (S - 1), fp32, no contraction.
+// The round trip normalise -> unnormalise decides floor() for on-lattice points (hard part 1).
+__device__ __forceinline__ float unnormalise(float n, float sm1) {
+    return __fmul_rn(__fmul_rn(__fadd_rn(n, 1.0f), 0.5f), sm1);
+}
+
+__device__ __forceinline__ void axis_weights(float u, int &i0, float &w0, float &w1) {
+    const float f = floorf(u);
+    // floorf of a huge / non-finite coordinate: clamp so the int conversion is defined; such samples
+    // are out of bounds on both corners anyway
+    const float fc = fminf(fmaxf(f, -2.0f), 1.0e9f);
+    i0 = (int)fc;
+    w1 = __fsub_rn(u, f);                    // ix - ix_tnw
+    w0 = __fsub_rn(__fadd_rn(f, 1.0f), u);   // ix_bse - ix
+}
+
+// Full sample for voxel (x,y,z) under beta `b`.  Z == 1: z pinned to 0 (weight 1 on slice 0).
+__device__ __forceinline__ Sample make_sample(const float *b, const Volume &vol, int xi, int yi, int zi) {
+    const float x = (float)xi, y = (float)yi, z = (float)zi;
+    Sample s;
+    s.ux = unnormalise(normalise(poly_q(b, 0, x, y, z), vol.sx1), vol.sx1);
+    s.uy = unnormalise(normalise(poly_q(b, 1, x, y, z), vol.sy1), vol.sy1);
+    axis_weights(s.ux, s.x0, s.wx0, s.wx1);
+    axis_weights(s.uy, s.y0, s.wy0, s.wy1);
+    if (vol.Z > 1) {
+        s.uz = unnormalise(normalise(poly_q(b, 2, x, y, z), vol.sz1), vol.sz1);
+        axis_weights(s.uz, s.z0, s.wz0, s.wz1);
+    } else {
+        s.uz = 0.0f, s.z0 = 0, s.wz0 = 1.0f, s.wz1 = 0.0f;
+    }
+    return s;
+}
+
+__device__ __forceinline__ bool in_range(int i, int n) { return (unsigned)i < (unsigned)n; }
+
+// Load the 30 coefficients of frame t from beta (10,3,T) into b[a*3+d].
+__device__ __forceinline__ void load_beta(const float *__restrict__ beta, int T, int t, float *b) {
+#pragma unroll
+    for (int i = 0; i < 30; ++i) b[i] = beta[(long)i * T + t];
+}
+
+// voxel index -> (x,y,z), p = (x*Y + y)*Z + z
+__device__ __forceinline__ void voxel_xyz(long p, const Volume &vol, int &x, int &y, int &z) {
+    const int yz = vol.Y * vol.Z;
+    x = (int)(p / yz);
+    const int rem = (int)(p - (long)x * yz);
+    y = rem / vol.Z;
+    z = rem - y * vol.Z;
+}
+
+}  // namespace dnmf

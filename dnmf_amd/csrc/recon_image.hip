@@ -1,0 +1,128 @@
+// Reconstruction image S[b,p] = sum_k C[k,t_b] A[p,k] on the fp32 matrix cores.
+//
+// The reference reconstructs a frame as einsum('tkmnz,kt->tmnz', A_t, C) AFTER warping all K
+// footprints (Demix/dNMF.py:56-58).  The trilinear gather is linear in the footprints, so the same
+// image is the gather of S = A.C; K2 then warps ONE channel instead of K.  S is a (P x K).(K x B)
+// product: v_mfma_f32_16x16x4_f32, voxels on the rows, frames on the columns.
+#include "common.hpp"
+
+namespace dnmf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One wave owns 16*NF frames and walks `groups_per_wave` groups of 16 voxels.
+//   MFMA A operand (16 voxels x 4 k):  lane l -> voxel l&15, k-slot l>>4
+//   MFMA B operand (4 k x 16 frames):  lane l -> k-slot l>>4, frame l&15
+// The reduction index is permuted so that k-slot q covers the contiguous channels [q*Kq, (q+1)*Kq)
+// (Kq = Kp/4): every lane then reads its footprint row with 16-byte loads.
+template <int NB, int NF>
+__global__ __launch_bounds__(256) void recon_image_kernel(const float *__restrict__ Apk, long P, int K, int Kp,
+                                                          const float *__restrict__ C, long ldc,
+                                                          const int *__restrict__ times, int B,
+                                                          float *__restrict__ S, long lds, int groups_per_wave) {
+    constexpr int KQ = 4 * NB;  // channels per k-slot
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int vi = lane & 15, q = lane >> 4;
+    const long ngroups = (P + 15) / 16;
+    const long g_begin = ((long)blockIdx.x * 4 + wave) * groups_per_wave;
+    if (g_begin >= ngroups) return;
+    const long g_end = g_begin + groups_per_wave < ngroups ? g_begin + groups_per_wave : ngroups;
+    const int f0 = blockIdx.y * 16 * NF;
+
+    // traces of this wave's frames: bq[nf][s] = C[q*KQ + s][t(f0 + 16 nf + vi)]
+    float bq[NF][KQ];
+    int tcol[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int f = f0 + 16 * nf + vi;
+        tcol[nf] = times[f < B ? f : B - 1];
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) {
+            const int ch = q * KQ + s;
+            bq[nf][s] = ch < K ? C[(long)ch * ldc + tcol[nf]] : 0.0f;
+        }
+    }
+
+    for (long g = g_begin; g < g_end; ++g) {
+        const long p0 = g * 16;
+        const long prow = p0 + vi < P ? p0 + vi : P - 1;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Apk + prow * Kp + q * KQ);
+        f32x4 a4[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a4[i] = src[i];
+        f32x4 acc[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], bq[nf][4 * i + e], acc[nf], 0, 0, 0);
+            }
+        }
+        // D[row = voxel 4q + r][col = frame vi]
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int f = f0 + 16 * nf + vi;
+            if (f < B) {
+                float *dst = S + (long)f * lds + p0 + 4 * q;
+                if (p0 + 4 * q + 3 < P) {
+                    *reinterpret_cast<f32x4 *>(dst) = acc[nf];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p0 + 4 * q + r < P) dst[r] = acc[nf][r];
+                }
+            }
+        }
+    }
+}
+
+template <int NB>
+static int launch_recon(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times, int B,
+                        float *S, long lds, hipStream_t stream) {
+    const long ngroups = (P + 15) / 16;
+    if (B > 16) {
+        constexpr int NF = 4;
+        const int fblocks = (B + 16 * NF - 1) / (16 * NF);
+        const int gpw = 64;
+        const long nwg = (ngroups + 4L * gpw - 1) / (4L * gpw);
+        hipLaunchKernelGGL((recon_image_kernel<NB, NF>), dim3((unsigned)nwg, (unsigned)fblocks), dim3(256), 0, stream,
+                           Apk, P, K, Kp, C, ldc, times, B, S, lds, gpw);
+    } else {
+        const int gpw = 16;
+        const long nwg = (ngroups + 4L * gpw - 1) / (4L * gpw);
+        hipLaunchKernelGGL((recon_image_kernel<NB, 1>), dim3((unsigned)nwg, 1u), dim3(256), 0, stream, Apk, P, K, Kp,
+                           C, ldc, times, B, S, lds, gpw);
+    }
+    return check_launch("dnmf_recon_image");
+}
+
+}  // namespace dnmf
+
+extern "C" int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times,
+                                int B, float *S, long lds, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(Apk && C && times && S, DNMF_E_NULL, "dnmf_recon_image: NULL buffer");
+    DNMF_REQUIRE(P > 0 && K > 0 && B > 0 && Kp == dnmf_padded_k(K) && ldc > 0 && lds >= P && lds % 4 == 0,
+                 DNMF_E_SHAPE, "dnmf_recon_image: P=%ld K=%d Kp=%d B=%d ldc=%ld lds=%ld (lds must be >= P and a multiple of 4)",
+                 P, K, Kp, B, ldc, lds);
+    DNMF_REQUIRE((reinterpret_cast<size_t>(S) & 15) == 0 && (reinterpret_cast<size_t>(Apk) & 15) == 0, DNMF_E_SHAPE,
+                 "dnmf_recon_image: S and Apk must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    switch (Kp / 16) {
+        case 1: return launch_recon<1>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 2: return launch_recon<2>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 3: return launch_recon<3>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 4: return launch_recon<4>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 5: return launch_recon<5>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 6: return launch_recon<6>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 7: return launch_recon<7>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 8: return launch_recon<8>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        default:
+            return fail(DNMF_E_UNSUPPORTED, "dnmf_recon_image: K=%d needs Kp=%d > 128 (not built yet)", K, Kp);
+    }
+}

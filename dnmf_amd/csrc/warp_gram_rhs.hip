@@ -1,0 +1,331 @@
+// K3 -- fused warp + per-frame Gram matrix + right-hand side on the fp32 matrix cores.
+//
+// Reference: the two large contractions of DeformableNMF.update_temporal,
+//   A_ts = einsum('mnzkt,mnzlt->klt', A_t, A_t)   (Demix/dNMF.py:141)
+//   C1   = einsum('mnzkt,mnzt->kt',  A_t, Y)      (Demix/dNMF.py:142)
+// on the warped footprints A_t that spatial_pushforward materialises for every frame in float64
+// (Demix/dNMF.py:69-87; 839 GB at 512x512x4000, K=100).  Here A_t exists only as MFMA operands.
+//
+// Shape of the computation.  For one frame, M = [A_t | y] is a (P x Kp) matrix (Kp = 16*NB, column K
+// carries the frame, the rest of the pad is zero) and the kernel needs the upper triangle of M^T M:
+// NT = NB(NB+1)/2 tiles of 16x16, each accumulated with v_mfma_f32_16x16x4_f32 over the voxels, four
+// voxels per instruction.  A wave owns ALL NT accumulator tiles (4*NT registers) for a contiguous chunk
+// of voxels of one frame, so it needs no LDS exchange and no barrier with other waves.
+//
+// Operand layout.  For v_mfma_f32_16x16x4_f32 lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]:
+// with k = voxel and i/j = channel the A and B fragments of a 16-channel block are the SAME register
+// (channel l&15 of voxel l>>4), so one k-step (4 voxels) needs NB fragment registers per lane.  The
+// channel <-> (block, lane) assignment is free (a Gram matrix is permutation-equivariant); it is chosen
+// so that a lane's NB values are contiguous runs of its footprint row (16/8/4-byte loads):
+//   blocks 4g..4g+3 -> channels 64g + 4i + (b-4g);  then a pair -> base + 2i + (b-b0);  then base + i.
+// The permutation is undone when the tiles are scattered into G (gram_finish_kernel).
+//
+// Warp.  Coordinates, floors and corner weights are computed once per voxel by one lane (64 voxels per
+// pass), parked in wave-private LDS and re-read as broadcasts by the 16 lanes that share the voxel.
+// The fp32 sequence for the coordinates is common.hpp's (bit-compatible with the reference's
+// normalise / grid_sample un-normalise round trip).
+#include "common.hpp"
+
+namespace dnmf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int K3_SS = 64;  // voxels per coordinate pass (one per lane)
+
+template <int NB>
+__host__ __device__ constexpr int chan_of(int b, int i) {
+    constexpr int NG4 = NB / 4, R = NB % 4, base = 64 * NG4;
+    if (b < 4 * NG4) return 64 * (b / 4) + 4 * i + (b % 4);
+    const int rb = b - 4 * NG4;
+    if (R == 1) return base + i;
+    if (R == 2) return base + 2 * i + rb;
+    return rb < 2 ? base + 2 * i + rb : base + 32 + i;  // R == 3
+}
+
+__host__ __device__ constexpr int tile_index(int NB, int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
+
+// NB fragment values of one footprint row for lane slot i (channel permutation above).
+template <int NB>
+struct RowFrag {
+    float v[NB];
+};
+
+template <int NB>
+__device__ __forceinline__ RowFrag<NB> load_row(const float *__restrict__ rp, int i) {
+    constexpr int NG4 = NB / 4, R = NB % 4, base = 64 * NG4;
+    RowFrag<NB> f;
+#pragma unroll
+    for (int g = 0; g < NG4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(rp + 64 * g + 4 * i);
+        f.v[4 * g + 0] = t[0], f.v[4 * g + 1] = t[1], f.v[4 * g + 2] = t[2], f.v[4 * g + 3] = t[3];
+    }
+    if constexpr (R == 1) {
+        f.v[4 * NG4] = rp[base + i];
+    } else if constexpr (R == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(rp + base + 2 * i);
+        f.v[4 * NG4] = t[0], f.v[4 * NG4 + 1] = t[1];
+    } else if constexpr (R == 3) {
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(rp + base + 2 * i);
+        f.v[4 * NG4] = t[0], f.v[4 * NG4 + 1] = t[1];
+        f.v[4 * NG4 + 2] = rp[base + 32 + i];
+    }
+    return f;
+}
+
+struct GramParams {
+    const float *Apk;
+    long a_frame_stride;
+    int Kp, K;
+    Volume vol;
+    const float *beta;
+    int T;
+    const int *times;
+    int B;
+    const float *frames;
+    long ldf;
+    const int *frame_ids;
+    float *slab;       // (B, nchunks, NT, 64, 4)
+    int nchunks;
+    long chunk_len;    // voxels per chunk, multiple of K3_SS
+};
+
+// NTAP = 4 (Z == 1, bilinear) or 8 (trilinear).  Tap c: dx = c&1, dy = (c>>1)&1, dz = c>>2 (ATen's corner order).
+template <int NB, int NTAP>
+__global__ __launch_bounds__(256) void warp_gram_kernel(GramParams p) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NQ = NTAP / 4;
+    __shared__ i32x4 s_row[4][NQ][K3_SS];
+    __shared__ f32x4 s_w[4][NQ][K3_SS];
+    __shared__ float s_y[4][K3_SS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + wave;  // chunk-major: neighbours share footprint rows in L2
+    if (item >= (long)p.nchunks * p.B) return;      // whole wave leaves; no workgroup barrier below
+    const int chunk = (int)(item / p.B);
+    const int b = (int)(item - (long)chunk * p.B);
+    const int t = p.times ? p.times[b] : b;
+    const float *__restrict__ Ab = p.Apk + (long)b * p.a_frame_stride;
+    const float *__restrict__ yb = p.frames + (long)(p.frame_ids ? p.frame_ids[b] : b) * p.ldf;
+    const Volume vol = p.vol;
+    const int Kp = p.Kp;
+
+    float bt[30];
+    load_beta(p.beta, p.T, t, bt);
+
+    const int ci = lane & 15;   // channel slot
+    const int vq = lane >> 4;   // voxel slot inside a k-step
+    int ysel = -1;              // block whose channel for this lane is the frame column K
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb)
+        if (chan_of<NB>(bb, ci) == p.K) ysel = bb;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long v_begin = (long)chunk * p.chunk_len;
+    const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
+
+    for (long vbase = v_begin; vbase < v_end; vbase += K3_SS) {
+        // ---- coordinate pass: lane -> voxel vbase + lane ------------------------------------------
+        {
+            const long v = vbase + lane;
+            int rows[NTAP];
+            float w[NTAP];
+            float yv = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NTAP; ++c) rows[c] = 0, w[c] = 0.0f;
+            if (v < v_end) {
+                int x, y, z;
+                voxel_xyz(v, vol, x, y, z);
+                const Sample s = make_sample(bt, vol, x, y, z);
+#pragma unroll
+                for (int c = 0; c < NTAP; ++c) {
+                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                    const int cx = s.x0 + dx, cy = s.y0 + dy, cz = s.z0 + dz;
+                    const bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z);
+                    const float wc = __fmul_rn(__fmul_rn(dx ? s.wx1 : s.wx0, dy ? s.wy1 : s.wy0), dz ? s.wz1 : s.wz0);
+                    w[c] = ok ? wc : 0.0f;
+                    rows[c] = ok ? ((cx * vol.Y + cy) * vol.Z + cz) * Kp : 0;
+                }
+                yv = yb[v];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                s_row[wave][q][lane] = i32x4{rows[4 * q], rows[4 * q + 1], rows[4 * q + 2], rows[4 * q + 3]};
+                s_w[wave][q][lane] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            }
+            s_y[wave][lane] = yv;
+        }
+        // LDS traffic of one wave is processed in order; only the compiler has to be kept from reordering
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- 16 k-steps of 4 voxels ------------------------------------------------------------------
+        // Software pipeline, distance one: the footprint rows of k-step ks+1 are requested before the
+        // MFMAs of k-step ks are issued, so their latency hides behind 28 x 32 matrix-core cycles.
+        RowFrag<NB> raw[NTAP];
+        f32x4 wcur[NQ];
+        float ycur;
+        auto issue = [&](int ks) {
+            const int vi = ks * 4 + vq;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const i32x4 rr = s_row[wave][q][vi];
+                wcur[q] = s_w[wave][q][vi];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[4 * q + e] = load_row<NB>(Ab + rr[e], ci);
+            }
+            ycur = s_y[wave][vi];
+        };
+        issue(0);
+#pragma unroll 2
+        for (int ks = 0; ks < K3_SS / 4; ++ks) {
+            // keep the consumer of the previous request from being hoisted above these MFMAs' issue
+            // point: it would wait for loads that were requested a few instructions earlier
+            __builtin_amdgcn_sched_barrier(0);
+            float frag[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) frag[bb] = raw[0].v[bb] * wcur[0][0];
+#pragma unroll
+            for (int c = 1; c < NTAP; ++c) {
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) frag[bb] = fmaf(raw[c].v[bb], wcur[c >> 2][c & 3], frag[bb]);
+            }
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) frag[bb] = (bb == ysel) ? ycur : frag[bb];
+            if (ks + 1 < K3_SS / 4) issue(ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj) {
+                    const int idx = tile_index(NB, bi, bj);
+                    acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[bi], frag[bj], acc[idx], 0, 0, 0);
+                }
+            }
+        }
+        // the next coordinate pass overwrites the records: keep it behind this pass's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    f32x4 *out = reinterpret_cast<f32x4 *>(p.slab) + (((long)b * p.nchunks + chunk) * NT) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[(long)i * 64] = acc[i];
+}
+
+// Ordered sum of the chunk partials of one frame and scatter into G (K,K) / r (K) with the channel
+// permutation undone.  D-tile element (row 4*(lane>>4)+reg, col lane&15) of tile (bi,bj).
+template <int NB>
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restrict__ slab, int nchunks, int K,
+                                                          float *__restrict__ G, float *__restrict__ r) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    const int b = blockIdx.x;
+    const int e = threadIdx.x;  // element inside a tile: lane*4 + reg
+    const int lane = e >> 2, reg = e & 3;
+    const int i = 4 * (lane >> 4) + reg, j = lane & 15;
+    float *Gb = G + (long)b * K * K;
+    float *rb = r + (long)b * K;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+            const int idx = tile_index(NB, bi, bj);
+            const float *src = slab + (((long)b * nchunks) * NT + idx) * 256 + e;
+            float s = 0.0f;
+            for (int c = 0; c < nchunks; ++c) s += src[(long)c * NT * 256];
+            const int k = chan_of<NB>(bi, i), l = chan_of<NB>(bj, j);
+            if (k < K && l < K) {
+                Gb[(long)k * K + l] = s;
+                Gb[(long)l * K + k] = s;
+            } else if (k < K && l == K) {
+                rb[k] = s;
+            } else if (k == K && l < K) {
+                rb[l] = s;
+            }
+        }
+    }
+}
+
+static void choose_chunks(long P, int B, int &nchunks, long &chunk_len) {
+    const long nss = (P + K3_SS - 1) / K3_SS;  // coordinate passes per frame
+    long want = (4096 + B - 1) / B;            // aim for >= 4096 wave-sized work items
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    if (want > nss) want = nss;
+    const long ss_per_chunk = (nss + want - 1) / want;
+    chunk_len = ss_per_chunk * K3_SS;
+    nchunks = (int)((P + chunk_len - 1) / chunk_len);
+}
+
+template <int NB>
+static int launch_gram(GramParams p, float *G, float *r, hipStream_t st) {
+    const long nitems = (long)p.nchunks * p.B;
+    const unsigned nwg = (unsigned)((nitems + 3) / 4);
+    if (p.vol.Z > 1)
+        hipLaunchKernelGGL((warp_gram_kernel<NB, 8>), dim3(nwg), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((warp_gram_kernel<NB, 4>), dim3(nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gram_finish_kernel<NB>), dim3((unsigned)p.B), dim3(256), 0, st, p.slab, p.nchunks, p.K, G, r);
+    return check_launch("dnmf_warp_gram_rhs");
+}
+
+}  // namespace dnmf
+
+extern "C" {
+
+size_t dnmf_warp_gram_rhs_workspace(long P, int K, int B) {
+    if (P <= 0 || K <= 0 || B <= 0) return 0;
+    const int NB = dnmf_padded_k(K) / 16;
+    int nchunks;
+    long chunk_len;
+    dnmf::choose_chunks(P, B, nchunks, chunk_len);
+    return (size_t)B * nchunks * (NB * (NB + 1) / 2) * 256 * sizeof(float);
+}
+
+int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z, const float *beta,
+                       int T, const int *times, int B, const float *frames, long ldf, const int *frame_ids, float *G,
+                       float *r, void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(Apk && beta && frames && G && r && workspace, DNMF_E_NULL, "dnmf_warp_gram_rhs: NULL buffer");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && Kp == dnmf_padded_k(K), DNMF_E_SHAPE,
+                 "dnmf_warp_gram_rhs: X=%d Y=%d Z=%d K=%d Kp=%d T=%d B=%d", X, Y, Z, K, Kp, T, B);
+    GramParams p;
+    p.vol = make_volume(X, Y, Z);
+    DNMF_REQUIRE(ldf >= p.vol.P && a_frame_stride >= 0, DNMF_E_SHAPE, "dnmf_warp_gram_rhs: ldf=%ld < P=%ld", ldf,
+                 p.vol.P);
+    DNMF_REQUIRE(p.vol.P * Kp < (1L << 31), DNMF_E_UNSUPPORTED,
+                 "dnmf_warp_gram_rhs: P*Kp=%ld does not fit 32-bit row offsets", p.vol.P * Kp);
+    DNMF_REQUIRE((reinterpret_cast<size_t>(Apk) & 15) == 0 && (a_frame_stride % 4) == 0 &&
+                     (reinterpret_cast<size_t>(workspace) & 15) == 0,
+                 DNMF_E_SHAPE, "dnmf_warp_gram_rhs: Apk / workspace must be 16-byte aligned");
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_gram_rhs_workspace(p.vol.P, K, B), DNMF_E_WORKSPACE,
+                 "dnmf_warp_gram_rhs: workspace %zu < %zu bytes", workspace_bytes,
+                 dnmf_warp_gram_rhs_workspace(p.vol.P, K, B));
+    p.Apk = Apk, p.a_frame_stride = a_frame_stride, p.Kp = Kp, p.K = K;
+    p.beta = beta, p.T = T, p.times = times, p.B = B;
+    p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
+    p.slab = static_cast<float *>(workspace);
+    choose_chunks(p.vol.P, B, p.nchunks, p.chunk_len);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Kp / 16) {
+        case 1: return launch_gram<1>(p, G, r, st);
+        case 2: return launch_gram<2>(p, G, r, st);
+        case 3: return launch_gram<3>(p, G, r, st);
+        case 4: return launch_gram<4>(p, G, r, st);
+        case 5: return launch_gram<5>(p, G, r, st);
+        case 6: return launch_gram<6>(p, G, r, st);
+        case 7: return launch_gram<7>(p, G, r, st);
+        case 8: return launch_gram<8>(p, G, r, st);
+        default:
+            return fail(DNMF_E_UNSUPPORTED, "dnmf_warp_gram_rhs: K=%d needs Kp=%d > 128 (not built yet)", K, Kp);
+    }
+}
+
+}  // extern "C"

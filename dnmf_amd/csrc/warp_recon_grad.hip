@@ -1,0 +1,210 @@
+// K2 -- one mini-batch of the motion step, fused: warp, reconstruction, squared error and the
+// analytic gradient with respect to beta.
+//
+// Reference: DeformableNMF.update_motion, Demix/dNMF.py:186-190 = ExponentialFP.forward
+// (dNMF.py:54-58) + F.mse_loss (dNMF.py:188) + autograd backward through grid_sample (w.r.t. the
+// grid), the normalisation and the einsum with the quadratic basis.  With s = A.C_t (dnmf_recon_image)
+//   A_tC(v)      = sum_corners w_c(v) s(corner_c(v))
+//   d A_tC / d q = sum_corners (d w_c / d q) s(corner_c(v))          (in-bounds corners only)
+//   d L / d beta[a,d] = 2/(B P) sum_v basis_a(v) (A_tC(v) - y(v)) dA_tC/dq_d(v)
+// The factor (S-1)/2 of grid_sample's backward and the 2/(S-1) of the normalisation cancel.
+#include "common.hpp"
+
+namespace dnmf {
+
+constexpr int K2_VPT = 8;             // voxels per thread
+constexpr int K2_VPB = 256 * K2_VPT;  // voxels per block
+constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
+                                                              const int *__restrict__ s_ids,
+                                                              const float *__restrict__ frames, long ldf,
+                                                              const int *__restrict__ frame_ids,
+                                                              const float *__restrict__ gout, Volume vol,
+                                                              const float *__restrict__ beta, int T,
+                                                              const int *__restrict__ times,
+                                                              float *__restrict__ recon, float *__restrict__ partial) {
+    const int b = blockIdx.y;
+    const float *s = S + (long)(s_ids ? s_ids[b] : b) * lds;
+    const float *y = frames ? frames + (long)(frame_ids ? frame_ids[b] : b) * ldf : nullptr;
+    float bt[30];
+    load_beta(beta, T, times[b], bt);
+
+    float acc[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i) acc[i] = 0.0f;
+    float sq = 0.0f;
+    const int YZ = vol.Y * vol.Z;
+
+    for (int i = 0; i < K2_VPT; ++i) {
+        const long p = (long)blockIdx.x * K2_VPB + i * 256 + threadIdx.x;
+        if (p >= vol.P) break;
+        int x, yy, z;
+        voxel_xyz(p, vol, x, yy, z);
+        const Sample sm = make_sample(bt, vol, x, yy, z);
+        float rec = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        const int nz = vol.Z > 1 ? 2 : 1;
+        for (int dz = 0; dz < nz; ++dz) {
+            const int cz = sm.z0 + dz;
+            const float wz = dz ? sm.wz1 : sm.wz0;
+            const float sgz = dz ? 1.0f : -1.0f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int cy = sm.y0 + dy;
+                const float wy = dy ? sm.wy1 : sm.wy0;
+                const float sgy = dy ? 1.0f : -1.0f;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int cx = sm.x0 + dx;
+                    const float wx = dx ? sm.wx1 : sm.wx0;
+                    const float sgx = dx ? 1.0f : -1.0f;
+                    if (in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z)) {
+                        const float val = s[(long)cx * YZ + cy * vol.Z + cz];
+                        rec = fmaf(val, wx * wy * wz, rec);
+                        gx = fmaf(val, sgx * wy * wz, gx);
+                        gy = fmaf(val, wx * sgy * wz, gy);
+                        gz = fmaf(val, wx * wy * sgz, gz);
+                    }
+                }
+            }
+        }
+        if (recon) recon[(long)b * vol.P + p] = rec;
+        // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
+        const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
+        sq = fmaf(resid, resid, sq);
+        const float xf = (float)x, yf = (float)yy, zf = (float)z;
+        const float basis[10] = {1.0f, xf, yf, zf, xf * xf, yf * yf, zf * zf, xf * yf, xf * zf, yf * zf};
+        const float g0 = resid * gx, g1 = resid * gy, g2 = vol.Z > 1 ? resid * gz : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 10; ++a) {
+            acc[a * 3 + 0] = fmaf(basis[a], g0, acc[a * 3 + 0]);
+            acc[a * 3 + 1] = fmaf(basis[a], g1, acc[a * 3 + 1]);
+            acc[a * 3 + 2] = fmaf(basis[a], g2, acc[a * 3 + 2]);
+        }
+    }
+
+    // block reduction: butterflies inside each wave, then the four wave leaders through LDS
+    __shared__ float red[4][K2_NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 30; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    {
+        const float v = wave_sum(sq);
+        if (lane == 0) red[wave][30] = v, red[wave][31] = 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x < K2_NACC) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        partial[((long)b * gridDim.x + blockIdx.x) * K2_NACC + threadIdx.x] = v;
+    }
+}
+
+// log|det J| at a point, literally Demix/dNMF.py:107-122 (rows 8/9 used as yz/xz there).
+__device__ float log_det_jac_dev(const float *b, float x, float y, float z) {
+    float J[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        J[0][c] = b[3 + c] + 2.0f * b[12 + c] * x + b[21 + c] * y + b[27 + c] * z;
+        J[1][c] = b[6 + c] + 2.0f * b[15 + c] * y + b[21 + c] * x + b[24 + c] * z;
+        J[2][c] = b[9 + c] + 2.0f * b[18 + c] * z + b[24 + c] * y + b[27 + c] * x;
+    }
+    const float a = J[0][0], bb = J[1][0], c = J[2][0], d = J[0][1], e = J[1][1], f = J[2][1], g = J[0][2],
+                h = J[1][2], i = J[2][2];
+    const float det = a * (e * i - f * h) - bb * (d * i - f * g) + c * (d * h - e * g);
+    return logf(fabsf(det));
+}
+
+// One block per frame: ordered sum of the per-block partials, scale, add into grad, per-frame loss, reg.
+__global__ __launch_bounds__(64) void warp_recon_grad_finish_kernel(const float *__restrict__ partial, int nblk,
+                                                                    Volume vol, const float *__restrict__ beta, int T,
+                                                                    const int *__restrict__ times, int B,
+                                                                    float grad_scale, float *__restrict__ grad,
+                                                                    float *__restrict__ frame_loss,
+                                                                    float *__restrict__ reg) {
+    const int b = blockIdx.x;
+    const int t = times[b];
+    const int j = threadIdx.x;
+    const float inv_n = 1.0f / ((float)B * (float)vol.P);
+    if (j < 31) {
+        const float *src = partial + (long)b * nblk * K2_NACC + j;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four interleaved chains, fixed order
+        int k = 0;
+        for (; k + 3 < nblk; k += 4) {
+            s0 += src[(long)(k + 0) * K2_NACC];
+            s1 += src[(long)(k + 1) * K2_NACC];
+            s2 += src[(long)(k + 2) * K2_NACC];
+            s3 += src[(long)(k + 3) * K2_NACC];
+        }
+        for (; k < nblk; ++k) s0 += src[(long)k * K2_NACC];
+        const float tot = (s0 + s1) + (s2 + s3);
+        if (j < 30) {
+            if (grad) grad[(long)j * T + t] += grad_scale * tot;
+        } else if (frame_loss) {
+            frame_loss[b] = tot * inv_n;
+        }
+    }
+    if (j == 32 && reg) {
+        float bt[30];
+        load_beta(beta, T, t, bt);
+        const float l1 = log_det_jac_dev(bt, vol.sx1, vol.sy1, vol.sz1);
+        const float l0 = log_det_jac_dev(bt, 0.0f, 0.0f, 0.0f);
+        reg[b] = l1 * l1 + l0 * l0;
+    }
+}
+
+__global__ __launch_bounds__(64) void sum_loss_kernel(const float *__restrict__ frame_loss, int B,
+                                                      float *__restrict__ loss) {
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < B; i += 64) v += frame_loss[i];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) loss[0] = v;
+}
+
+}  // namespace dnmf
+
+extern "C" {
+
+size_t dnmf_warp_recon_grad_workspace(long P, int B) {
+    if (P <= 0 || B <= 0) return 0;
+    const long nblk = (P + dnmf::K2_VPB - 1) / dnmf::K2_VPB;
+    return (size_t)B * nblk * dnmf::K2_NACC * sizeof(float) + (size_t)B * sizeof(float);
+}
+
+int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
+                         const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta, int T,
+                         const int *times, int B, float *recon, float *grad, float *loss, float *frame_loss, float *reg,
+                         void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(S && (frames || gout) && beta && times && workspace, DNMF_E_NULL,
+                 "dnmf_warp_recon_grad: NULL input");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && T > 0 && B > 0 && B <= 65535, DNMF_E_SHAPE,
+                 "dnmf_warp_recon_grad: X=%d Y=%d Z=%d T=%d B=%d", X, Y, Z, T, B);
+    const Volume vol = make_volume(X, Y, Z);
+    DNMF_REQUIRE(lds >= vol.P && (!frames || ldf >= vol.P), DNMF_E_SHAPE, "dnmf_warp_recon_grad: lds=%ld ldf=%ld < P=%ld", lds,
+                 ldf, vol.P);
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(vol.P, B), DNMF_E_WORKSPACE,
+                 "dnmf_warp_recon_grad: workspace %zu < %zu bytes", workspace_bytes,
+                 dnmf_warp_recon_grad_workspace(vol.P, B));
+    const int nblk = (int)((vol.P + K2_VPB - 1) / K2_VPB);
+    float *partial = static_cast<float *>(workspace);
+    float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(warp_recon_grad_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds, s_ids,
+                       frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
+    const float grad_scale = gout ? 1.0f : 2.0f / ((float)B * (float)vol.P);
+    hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T,
+                       times, B, grad_scale, grad, (loss || frame_loss) ? fl : nullptr, reg);
+    if (loss) hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(64), 0, st, fl, B, loss);
+    return check_launch("dnmf_warp_recon_grad");
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""Thin torch-tensor front end of the C ABI: validates device/dtype/contiguity, passes raw pointers and
+the current HIP stream.  torch is plumbing here (device memory, streams); all arithmetic happens in
+libdnmf_hip.so."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous float32 CUDA tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def _i32(t, device) -> torch.Tensor:
+    if isinstance(t, torch.Tensor):
+        return t.to(device=device, dtype=torch.int32).contiguous()
+    return torch.tensor(list(t), dtype=torch.int32, device=device)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def padded_k(K: int) -> int:
+    return _lib.load().dnmf_padded_k(int(K))
+
+
+def pack_footprints(A: torch.Tensor) -> torch.Tensor:
+    """A (..., K) -> packed (P, Kp) zero-padded copy the Gram / recon kernels read."""
+    K = A.shape[-1]
+    A2 = _f32(A.reshape(-1, K), "A")
+    Kp = padded_k(K)
+    out = torch.empty((A2.shape[0], Kp), dtype=torch.float32, device=A.device)
+    _lib.check(_lib.load().dnmf_pack_footprints(A2.data_ptr(), A2.shape[0], K, out.data_ptr(), Kp, _stream()),
+               "dnmf_pack_footprints")
+    return out
+
+
+def warp_gather(A: torch.Tensor, beta: torch.Tensor, times, want_A_t=True, want_grid=True):
+    """K1.  A (X,Y,Z,K), beta (10,3,T) -> A_t (B,K,X,Y,Z), grid (X,Y,Z,3,B)."""
+    X, Y, Z, K = A.shape
+    _f32(A, "A"), _f32(beta, "beta")
+    tt = _i32(times, A.device)
+    B = tt.numel()
+    A_t = torch.empty((B, K, X, Y, Z), dtype=torch.float32, device=A.device) if want_A_t else None
+    grid = torch.empty((X, Y, Z, 3, B), dtype=torch.float32, device=A.device) if want_grid else None
+    _lib.check(_lib.load().dnmf_warp_gather(A.data_ptr(), X, Y, Z, K, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B,
+                                            _ptr(A_t), _ptr(grid), _stream()), "dnmf_warp_gather")
+    return A_t, grid
+
+
+def recon_image(Apk: torch.Tensor, K: int, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
+    """S[b,p] = sum_k C[k,times[b]] A[p,k].  Apk (P,Kp), C (K,T) -> (B,P)."""
+    _f32(Apk, "Apk"), _f32(C, "C")
+    P, Kp = Apk.shape
+    tt = _i32(times, Apk.device)
+    B = tt.numel()
+    lds = (P + 3) // 4 * 4
+    if out is None:
+        out = torch.empty((B, lds), dtype=torch.float32, device=Apk.device)
+    if out.shape[0] < B or out.stride(0) % 4 or out.stride(0) < P or out.stride(1) != 1:
+        raise ValueError("recon_image: out must be (>=B, ld) with ld >= P and ld % 4 == 0")
+    _lib.check(_lib.load().dnmf_recon_image(Apk.data_ptr(), P, K, Kp, C.data_ptr(), C.stride(0), tt.data_ptr(), B,
+                                            out.data_ptr(), out.stride(0), _stream()), "dnmf_recon_image")
+    return out
+
+
+def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gout=None, want_recon=False,
+                    want_loss=True, want_reg=True, workspace=None):
+    """K2.  S (>=B, lds) recon images, frames (>=B, ldf) or None with gout (B,P).
+    Returns dict(recon, loss, frame_loss, reg); ``grad`` (10,3,T) is incremented in place."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    dev = beta.device
+    _f32(beta, "beta")
+    tt = _i32(times, dev)
+    B = tt.numel()
+    lib = _lib.load()
+    need = lib.dnmf_warp_recon_grad_workspace(P, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    recon = torch.empty((B, P), dtype=torch.float32, device=dev) if want_recon else None
+    loss = torch.empty((1,), dtype=torch.float32, device=dev) if want_loss else None
+    frame_loss = torch.empty((B,), dtype=torch.float32, device=dev) if want_loss else None
+    reg = torch.empty((B,), dtype=torch.float32, device=dev) if want_reg else None
+    sid = _i32(s_ids, dev) if s_ids is not None else None
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    if frames is not None and (frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda):
+        raise ValueError("warp_recon_grad: frames must be float32 CUDA with unit inner stride")
+    if gout is not None:
+        _f32(gout, "gout")
+    _lib.check(lib.dnmf_warp_recon_grad(
+        S.data_ptr(), S.stride(0), _ptr(sid), _ptr(frames), 0 if frames is None else frames.stride(0), _ptr(fid),
+        _ptr(gout), X, Y, Z, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B, _ptr(recon), _ptr(grad), _ptr(loss),
+        _ptr(frame_loss), _ptr(reg), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
+        "dnmf_warp_recon_grad")
+    return {"recon": recon, "loss": loss, "frame_loss": frame_loss, "reg": reg, "workspace": workspace}
+
+
+def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_stride=0, workspace=None):
+    """K3.  Returns G (B,K,K), r (B,K) for the frames listed."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    dev = Apk.device
+    _f32(Apk, "Apk"), _f32(beta, "beta")
+    lib = _lib.load()
+    tt = _i32(times, dev) if times is not None else None
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = tt.numel() if tt is not None else (fid.numel() if fid is not None else frames.shape[0])
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("warp_gram_rhs: frames must be float32 CUDA with unit inner stride")
+    need = lib.dnmf_warp_gram_rhs_workspace(P, K, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
+    r = torch.empty((B, K), dtype=torch.float32, device=dev)
+    _lib.check(lib.dnmf_warp_gram_rhs(
+        Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, beta.data_ptr(), beta.shape[2], _ptr(tt), B,
+        frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()), "dnmf_warp_gram_rhs")
+    return G, r, workspace
+
+
+def mu_temporal(G, r, C, iters: int):
+    """K4 without the neighbour term: C (K,T) fp32 updated in place."""
+    _f32(G, "G"), _f32(r, "r")
+    if not (C.is_cuda and C.dtype == torch.float32 and C.stride(1) == 1):
+        raise ValueError("mu_temporal: C must be float32 CUDA with unit inner stride")
+    T, K = r.shape
+    _lib.check(_lib.load().dnmf_mu_temporal(G.data_ptr(), r.data_ptr(), C.data_ptr(), C.stride(0), K, T, int(iters),
+                                            _stream()), "dnmf_mu_temporal")
+    return C
+
+
+def mu_temporal_step(G, r, Cin, Cout, gamma: float, c_left=None, c_right=None):
+    """K4, one round with the neighbour term; Cin/Cout (K,T) float64."""
+    _f32(G, "G"), _f32(r, "r")
+    for t, n in ((Cin, "Cin"), (Cout, "Cout")):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.stride(1) == 1):
+            raise ValueError(f"mu_temporal_step: {n} must be float64 CUDA with unit inner stride")
+    T, K = r.shape
+    _lib.check(_lib.load().dnmf_mu_temporal_step(G.data_ptr(), r.data_ptr(), Cin.data_ptr(), Cout.data_ptr(),
+                                                 Cin.stride(0), K, T, float(gamma), _ptr(c_left), _ptr(c_right),
+                                                 _stream()), "dnmf_mu_temporal_step")
+    return Cout

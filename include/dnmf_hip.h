@@ -1,0 +1,128 @@
+/*
+ * dnmf_hip.h -- C ABI of libdnmf_hip.so: the MI355X (gfx950) kernels of the deformable-NMF hot path.
+ *
+ * The reference (mathdiane/dNMF) has no FFI or plugin interface: its hot path is stock torch / numpy
+ * calls inside Demix/dNMF.py.  Each entry point below therefore replaces a group of those calls and
+ * cites them (paths relative to the reference root).  The Python mirror of the reference classes
+ * (dnmf_amd/Demix/dNMF.py) is the only caller; INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add to call the same functions from the original file.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns every buffer (torch allocates them); the library keeps no state between calls
+ *     other than the thread-local text behind dnmf_last_error();
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it and returns -- no host synchronisation, no allocation;
+ *   - return value: 0 = ok, negative = argument error (DNMF_E_*), positive = hipError_t;
+ *   - layouts are the reference's: a volume is (X,Y,Z) row-major with voxel index
+ *     p = (x*Y + y)*Z + z, P = X*Y*Z; footprints A are (P,K) (= torch (X,Y,Z,K) contiguous,
+ *     Demix/dNMF.py:39-40); beta is (10,3,T) contiguous (Demix/dNMF.py:24-27); traces C are (K,T)
+ *     with row stride ldc (Demix/dNMF.py:130); a frame is P floats;
+ *   - Z == 1 means "z pinned to slice 0" (the reference divides 0/0 there; see oracle/dnmf_oracle.py).
+ */
+#ifndef DNMF_HIP_H
+#define DNMF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNMF_ABI_VERSION 1
+
+#define DNMF_OK 0
+#define DNMF_E_NULL (-1)      /* required pointer is NULL */
+#define DNMF_E_SHAPE (-2)     /* non-positive or inconsistent size */
+#define DNMF_E_UNSUPPORTED (-3) /* valid request outside what this build handles (e.g. K too large) */
+#define DNMF_E_WORKSPACE (-4) /* workspace too small */
+
+typedef void *dnmf_stream_t;
+
+/* ABI version of the loaded library (DNMF_ABI_VERSION). */
+int dnmf_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *dnmf_last_error(void);
+
+/* ---- packed footprints ---------------------------------------------------------------------
+ * The Gram kernel reads footprints from a zero-padded copy with row length Kp = 16*ceil((K+1)/16)
+ * floats (16-byte aligned rows; one spare column carries the frame so that A_t^T y falls out of the
+ * same matrix product).  dnmf_padded_k returns Kp (0 if K < 1). */
+int dnmf_padded_k(int K);
+/* Apk (P,Kp) <- A (P,K), pad columns zeroed.  Replaces nothing in the reference (layout change). */
+int dnmf_pack_footprints(const float *A, long P, int K, float *Apk, int Kp, dnmf_stream_t stream);
+
+/* ---- K1: materialised warp ---------------------------------------------------------------------
+ * ExponentialFP.forward up to A_t (Demix/dNMF.py:54-57): q = basis.beta_t, n = 2q/(S-1)-1, zero-padded
+ * trilinear gather of all K channels (torch grid_sample, align_corners=True).
+ *   times  (B) int32 frame indices into beta's last axis
+ *   A_t    (B,K,X,Y,Z) or NULL;  grid (X,Y,Z,3,B) normalised coordinates or NULL */
+int dnmf_warp_gather(const float *A, int X, int Y, int Z, int K, const float *beta, int T,
+                     const int *times, int B, float *A_t, float *grid, dnmf_stream_t stream);
+
+/* ---- reconstruction image ------------------------------------------------------------------------
+ * S[b,p] = sum_k C[k,times[b]] * A[p,k]  (fp32 MFMA).  Because the trilinear gather is linear in the
+ * footprints, A_tC of Demix/dNMF.py:58 equals the gather of this single image; K2 consumes it.
+ *   Apk (P,Kp) packed footprints; C (K,T) row stride ldc; S (B,P) row stride lds (floats) */
+int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times,
+                     int B, float *S, long lds, dnmf_stream_t stream);
+
+/* ---- K2: fused warp + reconstruction + loss + d loss / d beta --------------------------------------
+ * One mini-batch of update_motion (Demix/dNMF.py:186-190): forward (dNMF.py:54-58), F.mse_loss
+ * (dNMF.py:188, mean over B*P) and its autograd gradient w.r.t. beta[:,:,times]; also reg of
+ * dNMF.py:60-61 (gradient-free in the reference).
+ *   S       recon images, frame b at S + s_ids[b]*lds (s_ids NULL -> b)
+ *   frames  video frames, frame b at frames + frame_ids[b]*ldf (frame_ids NULL -> b)
+ *   gout    NULL, or (B,P) upstream gradient d L / d A_tC of an arbitrary loss: then grad receives
+ *           its chain through the warp unscaled, `frames` may be NULL and loss / frame_loss are
+ *           meaningless (this is the backward of the autograd node the Python surface exposes)
+ *   recon   (B,P) A_tC or NULL
+ *   grad    (10,3,T): columns times[b] are INCREMENTED by the gradient (autograd .grad semantics);
+ *           times must not contain duplicates
+ *   loss    (1) mean squared error of the batch;  frame_loss (B) per-frame sum of squares / (B*P) or NULL
+ *   reg     (B) or NULL
+ *   workspace: dnmf_warp_recon_grad_workspace(P,B) bytes */
+size_t dnmf_warp_recon_grad_workspace(long P, int B);
+int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
+                         const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta,
+                         int T, const int *times, int B, float *recon, float *grad, float *loss,
+                         float *frame_loss, float *reg, void *workspace, size_t workspace_bytes,
+                         dnmf_stream_t stream);
+
+/* ---- K3: fused warp + per-frame Gram + rhs ---------------------------------------------------------
+ * The two large contractions of update_temporal (Demix/dNMF.py:141-142) on the warped footprints of
+ * spatial_pushforward (dNMF.py:69-87) without materialising A_t:
+ *   G[b] = A_t^T A_t (K,K),  r[b] = A_t^T y_b (K),  A_t = warp of A by beta[:,:,times[b]].
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32), upper triangle only, symmetric fill.
+ *   Apk      packed footprints; a_frame_stride 0 = one A for all frames, else floats between the
+ *            per-frame packed A of consecutive b (static update_temporal on an explicit A_t)
+ *   times    (B) or NULL (-> 0..B-1); frames / ldf / frame_ids as in K2
+ *   G (B,K,K), r (B,K); workspace: dnmf_warp_gram_rhs_workspace(P,K,B) bytes */
+size_t dnmf_warp_gram_rhs_workspace(long P, int K, int B);
+int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z,
+                       const float *beta, int T, const int *times, int B, const float *frames, long ldf,
+                       const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+                       dnmf_stream_t stream);
+
+/* ---- K4: multiplicative update of the traces --------------------------------------------------------
+ * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
+ * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.
+ *   G (T,K,K) symmetric, r (T,K)
+ *
+ * dnmf_mu_temporal: `iters` rounds without the neighbour term (gamma None or 0: frames independent, the
+ *   whole loop runs in registers); C (K,T) fp32 row stride ldc, in/out, rounded to fp32 once at the end
+ *   as dNMF.py:177 does.
+ * dnmf_mu_temporal_step: ONE round with the neighbour term on an fp64 state, Cin -> Cout (both (K,T),
+ *   row stride ldc, distinct buffers).  Neighbours of the first / last frame are replicated
+ *   (dNMF.py:145) unless c_left / c_right (K doubles: the adjacent frame owned by the neighbouring
+ *   T-shard) are given. */
+int dnmf_mu_temporal(const float *G, const float *r, float *C, long ldc, int K, int T, int iters,
+                     dnmf_stream_t stream);
+int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K,
+                          int T, double gamma, const double *c_left, const double *c_right,
+                          dnmf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNMF_HIP_H */

@@ -1,0 +1,120 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the header declares,
+argument validation works without a GPU, and the host-side simulator reproduces the reference video."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dnmf_amd.build import build_library
+    build_library()
+    from dnmf_amd import _lib
+    return _lib.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dnmf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dnmf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from dnmf_amd import _lib
+    names = header_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dnmf_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in dnmf_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_padding(lib):
+    assert lib.dnmf_version() == 1
+    assert [lib.dnmf_padded_k(k) for k in (0, 1, 10, 15, 16, 50, 100, 111, 112, 200)] == \
+        [0, 16, 16, 16, 32, 64, 112, 112, 128, 208]
+
+
+def test_argument_errors_are_reported_without_a_gpu(lib):
+    """Validation happens before any HIP call, so it can be exercised on a CPU-only box."""
+    rc = lib.dnmf_pack_footprints(None, 10, 3, None, 16, None)
+    assert rc == -1 and b"NULL" in lib.dnmf_last_error()
+    buf = ctypes.create_string_buffer(64)
+    addr = ctypes.addressof(buf)
+    rc = lib.dnmf_pack_footprints(addr, 10, 3, addr, 17, None)
+    assert rc == -2 and b"Kp" in lib.dnmf_last_error()
+    rc = lib.dnmf_mu_temporal(addr, addr, addr, 4, 300, 4, 1, None)
+    assert rc == -3
+    rc = lib.dnmf_warp_gram_rhs(addr, 16, 3, 0, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr, 8, None)
+    assert rc in (-2, -4)  # alignment or workspace, never a launch
+    assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 2 * 28 * 256 * 4
+
+
+def test_product_has_no_cpu_fallback():
+    """The classes need the HIP library and a GPU; on a CPU box construction raises instead of computing."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dnmf_amd.Demix import dNMF
+    with pytest.raises(Exception):
+        dNMF.ExponentialFP(torch.tensor([8, 8, 2]), 2, 3, positions=torch.zeros(2, 3))
+    import dnmf_amd
+    src = "".join(open(os.path.join(os.path.dirname(dnmf_amd.__file__), f)).read()
+                  for f in ("ops.py", "_lib.py", os.path.join("Demix", "dNMF.py")))
+    assert "oracle" not in src.replace("CPU oracle", "")
+
+
+def chan_of(NB, b, i):
+    """Python mirror of csrc/warp_gram_rhs.hip:chan_of -- the channel held by lane slot i for block b."""
+    ng4, r = divmod(NB, 4)
+    base = 64 * ng4
+    if b < 4 * ng4:
+        return 64 * (b // 4) + 4 * i + (b % 4)
+    rb = b - 4 * ng4
+    if r == 1:
+        return base + i
+    if r == 2:
+        return base + 2 * i + rb
+    return base + 2 * i + rb if rb < 2 else base + 32 + i
+
+
+@pytest.mark.parametrize("NB", range(1, 9))
+def test_gram_channel_permutation_is_a_bijection(NB):
+    seen = sorted(chan_of(NB, b, i) for b in range(NB) for i in range(16))
+    assert seen == list(range(16 * NB))
+
+
+def test_simulator_reproduces_reference_video():
+    from dnmf_amd.WUtils import Simulator as S
+    g = golden("G8_simulator")
+    par = {"sigma": [5, 5, .01], "ls": [10, 10, 10]}
+    for snr, key in ((-120, "video"), (-20, "video_noisy")):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        video, positions, traces = S.generate_video(3, 6, g["sz"], 3, .2, snr, 'exp', 'gp', par)
+        np.testing.assert_allclose(video.numpy(), g[key], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(positions.numpy(), g["positions"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(traces, g["traces"])
+    with pytest.raises(NotImplementedError):
+        S.generate_video(3, 6, [8, 8, 2], motion='sq')
+
+
+def test_dataset_protocol_and_in_place_clamp():
+    from dnmf_amd.Demix.dNMF import SimulatedVideoDataset
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = SimulatedVideoDataset(K=3, T=6, sz=torch.tensor([16, 16, 2]), shape_std=3, density=.2, bg_snr=-20,
+                               traces='exp', motion='gp', motion_par={"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    assert len(ds) == 6 and tuple(ds.video.shape) == (16, 16, 2, 6) and tuple(ds.positions.shape) == (3, 3, 6)
+    assert float(ds.video.min()) < 0
+    frame, idx = ds[2]
+    assert idx == 2 and float(frame.min()) >= 0 and float(ds.video[..., 2].min()) >= 0   # clamped in the store
+    assert float(ds.video[..., 3].min()) < 0
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
+    batch = next(iter(loader))
+    assert tuple(batch[0].shape) == (4, 16, 16, 2) and batch[1].tolist() == [0, 1, 2, 3]

@@ -1,0 +1,268 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (fp32 path vs the reference's fp32 warp / float64 NMF arithmetic):
+  A_t, A_tC   atol 2e-6   interpolation weights differ in rounding order only (values are O(1))
+  beta.grad   rtol 1e-4 of the largest component (sums over P voxels in a different order)
+  G, r        rtol 2e-5   fp32 MFMA chains + ordered chunk sums vs float64 einsum
+  C           rtol 1e-4   after up to 50 multiplicative rounds
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dnmf_amd.Demix import dNMF
+    return dNMF
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import dnmf_oracle
+    return dnmf_oracle
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def make_fp(M, sz, K, T, positions, beta=None, A=None):
+    fp = M.ExponentialFP(torch.as_tensor(np.asarray(sz)), K, T, positions=torch.as_tensor(np.asarray(positions)).float())
+    if A is not None:
+        fp.A = dev(A)
+    if beta is not None:
+        with torch.no_grad():
+            fp.beta.copy_(dev(beta))
+    return fp
+
+
+def test_G1_constructor(M):
+    g = golden("G1_init")
+    fp = make_fp(M, g["sz"], 3, 5, g["positions"])
+    np.testing.assert_array_equal(fp.flow_id.cpu().numpy(), g["lattice"])
+    np.testing.assert_array_equal(fp.transformed.cpu().numpy(), g["basis"])
+    np.testing.assert_array_equal(fp.beta.detach().cpu().numpy(), g["beta"])
+    assert fp.beta.requires_grad and fp.beta.is_leaf
+    np.testing.assert_allclose(fp.A.cpu().numpy(), g["A"], rtol=2e-6, atol=1e-30)  # device exp vs host exp
+
+
+def test_G2_forward(M, O):
+    g = golden("G2_forward")
+    A = O.gaussian_footprints(g["sz"], g["positions"], np.full(3, 3.0))
+    fp = make_fp(M, g["sz"], 3, 5, g["positions"], beta=g["beta"], A=A)
+    A_tC, A_t, grid, reg = fp(g["times"].tolist(), torch.from_numpy(g["C"]))
+    assert tuple(A_t.shape) == g["A_t"].shape and tuple(grid.shape) == g["grid"].shape
+    np.testing.assert_allclose(grid.cpu().numpy(), g["grid"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(A_t.cpu().numpy(), g["A_t"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(A_tC.detach().cpu().numpy(), g["A_tC"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(reg.cpu().numpy(), g["reg"], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("label", ["id_b1", "id_b3", "pert_b1", "pert_b3", "pert_b4"])
+def test_G3_beta_grad(M, O, label):
+    """Both routes to beta.grad: autograd through forward() and the fused mini-batch kernel."""
+    g = golden("G3_grad")
+    A = O.gaussian_footprints(g["sz"], g["positions"], np.full(4, 3.0))
+    times = g[label + "_times"].tolist()
+    frames = dev(np.moveaxis(g["video"][..., times], -1, 0))
+    want = g[label + "_grad"]
+    tol = 1e-4 * np.abs(want).max()
+
+    fp = make_fp(M, g["sz"], 4, 8, g["positions"], beta=g[label + "_beta"], A=A)
+    A_tC, _, _, _ = fp(times, torch.from_numpy(g["C"]))
+    loss = torch.nn.functional.mse_loss(A_tC, frames)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), g[label + "_loss"], rtol=1e-5)
+    np.testing.assert_allclose(fp.beta.grad.cpu().numpy(), want, rtol=1e-4, atol=tol)
+
+    from dnmf_amd import ops
+    fp2 = make_fp(M, g["sz"], 4, 8, g["positions"], beta=g[label + "_beta"], A=A)
+    S = ops.recon_image(fp2.packed_footprints(), 4, dev(g["C"]), times)
+    grad = torch.zeros_like(fp2.beta)
+    out = ops.warp_recon_grad(S, None, frames.reshape(len(times), -1), None, fp2.sz_list, fp2.beta.detach(), times,
+                              grad=grad)
+    np.testing.assert_allclose(float(out["loss"][0]), g[label + "_loss"], rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), want, rtol=1e-4, atol=tol)
+
+
+def test_G6_gram_rhs_and_G4_temporal(M, O):
+    from dnmf_amd import ops
+    g6, g4 = golden("G6_pushforward"), golden("G4_temporal")
+    A = O.gaussian_footprints(g6["sz"], g6["positions"], np.full(4, 3.0))
+    fp = make_fp(M, g6["sz"], 4, 8, g6["positions"], beta=g6["beta"], A=A)
+    frames = dev(np.moveaxis(g6["video"], -1, 0)).reshape(8, -1)
+    G, r, _ = ops.warp_gram_rhs(fp.packed_footprints(), 4, fp.sz_list, fp.beta.detach(), list(range(8)), frames)
+    Gref, rref = O.gram_rhs(g6["A_t"].astype(np.float64), g6["Y"].astype(np.float64))
+    np.testing.assert_allclose(G.cpu().numpy(), np.moveaxis(Gref, 2, 0), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(r.cpu().numpy(), rref.T, rtol=2e-5, atol=1e-7)
+    for label, gamma in (("none", None), ("zero", 0), ("g1e2", 1e-2)):
+        C1 = M._mu_temporal(G, r, dev(g4["C0"], torch.float64), gamma, 1)
+        np.testing.assert_allclose(C1.cpu().numpy(), g4[label + "_it1"], rtol=5e-5)
+        C50 = M._mu_temporal(G, r, dev(g4["C0"], torch.float64), gamma, 50)
+        np.testing.assert_allclose(C50.cpu().numpy(), g4[label + "_it50"], rtol=1e-4)
+    C50f = M._mu_temporal(G, r, dev(g4["C0"]), 0, 50)          # fp32 state, fused loop (update_footprints' route)
+    np.testing.assert_allclose(C50f.cpu().numpy(), g4["zero_it50"], rtol=1e-4)
+    # static update_temporal on an explicit A_t, numpy in / numpy out
+    C1 = M.DeformableNMF.update_temporal(g6["A_t"].astype(np.float64), g4["C0"], g6["Y"].astype(np.float64), gamma=1e-2)
+    np.testing.assert_allclose(C1, g4["g1e2_it1"], rtol=5e-5)
+
+
+def test_G5_update_spatial(M):
+    g = golden("G5_spatial")
+    np.testing.assert_allclose(M.DeformableNMF.update_spatial(g["A"], g["C"], g["Y_i"]), g["out_noD"], rtol=1e-10)
+    np.testing.assert_allclose(M.DeformableNMF.update_spatial(g["A"], g["C"], g["Y_i"], D=g["D"], gamma=0.7), g["out_D"],
+                               rtol=1e-10)
+
+
+def test_G6_pushforward_surface(M, O):
+    g = golden("G6_pushforward")
+    A = O.gaussian_footprints(g["sz"], g["positions"], np.full(4, 3.0))
+    dn = M.DeformableNMF(torch.from_numpy(g["sz"]), 4, 8, positions=torch.from_numpy(g["positions"]))
+    dn.fp.A = dev(A)
+    with torch.no_grad():
+        dn.fp.beta.copy_(dev(g["beta"]))
+    np.testing.assert_allclose(dn.D, g["D"], rtol=1e-10)
+    frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(g["video"], -1, 0)))
+    loader = [(frames[s:s + 3], torch.arange(s, min(8, s + 3))) for s in range(0, 8, 3)]
+    A_t, Y_i, Y = M.ExponentialFP.spatial_pushforward(loader, 3, g["sz"], "cuda", dn)
+    np.testing.assert_allclose(A_t, g["A_t"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(Y.astype(np.float32), g["Y"])
+
+
+@pytest.mark.parametrize("label", ["lr1e-5_ordered", "lr1e-3_ordered", "lr1e-3_shuffled"])
+def test_G9_demo_loop(M, O, label):
+    g = golden("G9_loop")
+    lr, epochs, shuffled, bs = g[label + "_cfg"]
+    bs = int(bs)
+    A = O.gaussian_footprints(g["sz"], g["positions"], np.full(4, 3.0))
+    dn = M.DeformableNMF(torch.from_numpy(g["sz"]), 4, 8, positions=torch.from_numpy(g["positions"]))
+    dn.verbose = False
+    dn.fp.A = dev(A)
+    dn.C = dev(g[label + "_C0"])
+    opt = torch.optim.Adam([dn.fp.beta], lr=float(lr))
+    frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(g["video"], -1, 0)))
+    order = [[[i for i in b if i >= 0] for b in ep] for ep in g[label + "_order"].tolist()]
+    for ep in order:
+        dn.update_motion([(frames[b], torch.tensor(b)) for b in ep], opt, gamma=1, epochs=1)
+    ident = O.identity_beta(8)
+    want = g[label + "_beta_after_motion"]
+    scale = np.abs(want - ident).max()
+    # Adam moves every coefficient by ~lr per step whatever the gradient's size: compare the displacement
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - ident, want - ident, rtol=0, atol=2e-3 * scale)
+    test = [(frames[s:s + bs], torch.arange(s, s + bs)) for s in range(0, 8, bs)]
+    A_t, Y_i, Y = dn.update_footprints(test, bs, g["sz"], gamma_c=0, iter_c=5)
+    assert A_t.shape == (20, 16, 2, 4, 8) and Y.shape == (20, 16, 2, 8) and Y_i.shape == Y.shape
+    np.testing.assert_allclose(dn.C.cpu().numpy(), g[label + "_C_after_footprints"], rtol=1e-4)
+
+
+def test_G10_z1_semantics(M):
+    g = golden("G10_2d")
+    X, Y, _ = g["sz"]
+    T = g["beta"].shape[2]
+    fp = make_fp(M, [int(X), int(Y), 1], 3, T, np.zeros((3, 3), np.float32), beta=g["beta"], A=g["A2d"][:, :, None, :])
+    times = list(range(T))
+    A_tC, A_t, grid, _ = fp(times, torch.from_numpy(g["C"]))
+    np.testing.assert_allclose(A_t.cpu().numpy()[..., 0], g["A_t"][..., 0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(A_tC.detach().cpu().numpy()[..., 0], g["A_tC"][..., 1], rtol=0, atol=2e-6)
+    frames = dev(np.moveaxis(g["Y2d"], -1, 0))[:, :, :, None]
+    loss = torch.nn.functional.mse_loss(A_tC, frames)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), g["loss"], rtol=1e-5)
+    grad = fp.beta.grad.cpu().numpy()
+    noz = [0, 1, 2, 4, 5, 7]
+    np.testing.assert_allclose(grad[noz, :2], g["grad"][noz, :2], rtol=1e-4, atol=1e-4 * np.abs(g["grad"]).max())
+    assert np.all(grad[:, 2] == 0) and np.all(grad[[3, 6, 8, 9]] == 0)
+    from dnmf_amd import ops
+    G, r, _ = ops.warp_gram_rhs(fp.packed_footprints(), 3, fp.sz_list, fp.beta.detach(), times, frames.reshape(T, -1))
+    C5 = M._mu_temporal(G, r, dev(g["C"]), 0, 5)
+    np.testing.assert_allclose(C5.cpu().numpy(), g["C_it5"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("sz,K,T", [([40, 36, 3], 20, 5), ([33, 47, 1], 50, 6), ([48, 40, 2], 100, 4),
+                                    ([21, 19, 2], 10, 9), ([32, 32, 1], 120, 3)])
+def test_random_problem_vs_oracle(M, O, sz, K, T):
+    """Every padded-K variant of the Gram kernel (NB = 1..8), ragged voxel counts, 2-D and 3-D."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(K)
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, 3.0))
+    beta = O.identity_beta(T)
+    beta += (rng.randn(10, 3, T) * np.array([0.7, 1e-2, 1e-2, 1e-2, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4])[:, None, None]
+             ).astype(np.float32)
+    if sz[2] == 1:
+        beta[:, 2] = O.identity_beta(T)[:, 2]
+    C = rng.rand(K, T).astype(np.float32)
+    video = rng.rand(*sz, T).astype(np.float32)
+    lat = O.voxel_lattice(sz)
+    basis = O.quadratic_basis(lat)
+    times = list(range(T))
+    A_tC, A_t, n, reg = O.forward(A, basis, beta, sz, times, C, O.trilinear_sample_torch)
+    fp = make_fp(M, sz, K, T, pos, beta=beta, A=A)
+    gA_tC, gA_t, ggrid, greg = fp(times, torch.from_numpy(C))
+    np.testing.assert_allclose(gA_t.cpu().numpy(), A_t, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(gA_tC.detach().cpu().numpy(), A_tC, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(greg.cpu().numpy(), reg, rtol=1e-3, atol=1e-7)
+    frames = np.moveaxis(video, -1, 0)
+    loss, grad = O.mse_beta_grad_autograd(A, basis, beta, sz, times, C, frames)
+    gl = torch.nn.functional.mse_loss(gA_tC, dev(frames))
+    gl.backward()
+    np.testing.assert_allclose(float(gl), loss, rtol=1e-5)
+    np.testing.assert_allclose(fp.beta.grad.cpu().numpy(), grad, rtol=1e-4, atol=1e-4 * np.abs(grad).max())
+    G, r, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), times, dev(frames).reshape(T, -1))
+    A64 = np.transpose(A_t.astype(np.float64), [2, 3, 4, 1, 0])
+    Gref, rref = O.gram_rhs(A64, video.astype(np.float64))
+    np.testing.assert_allclose(G.cpu().numpy(), np.moveaxis(Gref, 2, 0), rtol=2e-5, atol=2e-5 * np.abs(Gref).max())
+    np.testing.assert_allclose(r.cpu().numpy(), rref.T, rtol=2e-5, atol=2e-5 * np.abs(rref).max())
+    Cref = O.mu_temporal_from_gram(Gref, rref, C, None, 20)
+    Cg = M._mu_temporal(G, r, dev(C), None, 20)
+    np.testing.assert_allclose(Cg.cpu().numpy(), Cref, rtol=2e-4, atol=1e-7)
+
+
+def test_full_size_properties(M):
+    """512x512, K=100 (BASELINE config 3 geometry) through properties that need no CPU reference:
+    identity warp => the Gram matrix of every frame is A^T A; integer translation => Gram of the shifted
+    footprints; r is linear in the frame."""
+    from dnmf_amd import ops
+    torch.manual_seed(0)
+    sz, K, T = [512, 512, 1], 100, 6
+    pos = torch.rand(K, 3) * torch.tensor([512.0, 512.0, 0.0])
+    fp = M.ExponentialFP(torch.tensor(sz), K, T, positions=pos)
+    frames = torch.rand(T, 512 * 512, device="cuda")
+    with torch.no_grad():
+        fp.beta[0, 0, 1] = 3.0       # frame 1: shift +3 px in x
+        fp.beta[0, 1, 2] = -2.0      # frame 2: shift -2 px in y
+    G, r, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), list(range(T)), frames)
+    A2 = fp.A.reshape(-1, K).double()
+    G0 = (A2.T @ A2)
+    scale = float(G0.abs().max())
+    for t in (0, 3, 5):
+        assert float((G[t].double() - G0).abs().max()) < 2e-5 * scale
+        rt = A2.T @ frames[t].double()
+        assert float((r[t].double() - rt).abs().max()) < 2e-5 * float(rt.abs().max())
+    A3 = fp.A.reshape(512, 512, K)
+    sh = torch.zeros_like(A3)
+    sh[:-3] = A3[3:]                 # A_t(x,y) = A(x+3, y), zero beyond the edge
+    S2 = sh.reshape(-1, K).double()
+    assert float((G[1].double() - S2.T @ S2).abs().max()) < 2e-5 * scale
+    sh = torch.zeros_like(A3)
+    sh[:, 2:] = A3[:, :-2]
+    S2 = sh.reshape(-1, K).double()
+    assert float((G[2].double() - S2.T @ S2).abs().max()) < 2e-5 * scale
+    # linearity of the rhs in the frame
+    mix = (2.0 * frames[3] - 0.5 * frames[4])[None].contiguous()
+    with torch.no_grad():
+        b1 = fp.beta.detach()[:, :, 3:4].contiguous()
+    _, rmix, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, b1, [0], mix)
+    want = 2.0 * r[3] - 0.5 * r[4]
+    assert float((rmix[0] - want).abs().max()) < 1e-4 * float(want.abs().max())
+    # G symmetric and the multiplicative update keeps traces non-negative
+    assert torch.equal(G, G.transpose(1, 2))
+    C = M._mu_temporal(G, r, torch.rand(K, T, device="cuda"), None, 50)
+    assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
