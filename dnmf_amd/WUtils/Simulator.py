@@ -100,3 +100,39 @@ def generate_video(K, T, sz=[20, 20, 1], shape_std=3, density=.1, bg_snr=-1, tra
     frames += noise.permute(3, 0, 1, 2)
     frames /= frames.max()
     return frames.permute(1, 2, 3, 0), positions, tr
+
+
+def generate_video_resident(K, T, sz, shape_std=3, density=.1, bg_snr=-1, motion_par=None, device='cuda',
+                            t0=0, t1=None, noise=None, group=None):
+    """``generate_video(traces='exp', motion='gp')`` rendered on the GPU, frame-major and resident.
+
+    Positions and traces are drawn on the host exactly like ``generate_video`` (same numpy draws for the same
+    seed, for all T frames); frames ``t0..t1-1`` are rendered by ``dnmf_render_frames`` into a ``(t1-t0, P)``
+    fp32 CUDA tensor.  ``noise`` (X,Y,Z,T) or (T,P): background noise to add (already scaled); None draws
+    ``bg_std * N(0,1)`` with the device generator (a different stream from the reference's CPU draw).
+    ``group``: torch.distributed group when the T axis is sharded over ranks -- the two global
+    normalisers (sum of squares, maximum) are all-reduced so every rank holds its slice of ONE video.
+    Returns ``frames (t1-t0, P)``, ``positions (K,3,T)`` torch fp32 (host), ``traces (K,T)`` numpy float64."""
+    from .. import ops
+    t1 = T if t1 is None else t1
+    positions = generate_gp_motion(K, T, motion_par['sigma'], motion_par['ls'], sz)
+    tr = simulate_exponential_traces(K, T, density)
+    frames = ops.render_frames(positions.to(device).contiguous(), torch.from_numpy(tr).to(device).contiguous(), sz,
+                               shape_std, t0, t1 - t0)
+    energy = (frames.double() ** 2).sum()
+    if group is not None:
+        torch.distributed.all_reduce(energy, group=group)
+    frames /= energy.float()
+    bg_std = float(np.sqrt(10 ** (bg_snr / 10)))
+    if noise is None:
+        frames += bg_std * torch.randn(frames.shape, device=device)
+    else:
+        noise = torch.as_tensor(noise)
+        if noise.dim() == 4:
+            noise = noise.permute(3, 0, 1, 2).reshape(noise.shape[3], -1)
+        frames += noise[t0:t1].to(device)
+    peak = frames.max()
+    if group is not None:
+        torch.distributed.all_reduce(peak, op=torch.distributed.ReduceOp.MAX, group=group)
+    frames /= peak
+    return frames, positions, tr

@@ -29,6 +29,7 @@ SIGNATURES = {
                                 _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
+    "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
 }
 
 _lib = None

@@ -8,8 +8,28 @@ import torch
 from . import _lib
 
 
+# bench.py sets TIMING = {} to collect (start, end) HIP events around the named kernels, on their stream
+TIMING = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            TIMING.setdefault(self.name, []).append((self.a, b))
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -97,11 +117,13 @@ def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gou
         raise ValueError("warp_recon_grad: frames must be float32 CUDA with unit inner stride")
     if gout is not None:
         _f32(gout, "gout")
-    _lib.check(lib.dnmf_warp_recon_grad(
-        S.data_ptr(), S.stride(0), _ptr(sid), _ptr(frames), 0 if frames is None else frames.stride(0), _ptr(fid),
-        _ptr(gout), X, Y, Z, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B, _ptr(recon), _ptr(grad), _ptr(loss),
-        _ptr(frame_loss), _ptr(reg), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
-        "dnmf_warp_recon_grad")
+    with _timed("warp_recon_grad"):
+        rc = lib.dnmf_warp_recon_grad(
+            S.data_ptr(), S.stride(0), _ptr(sid), _ptr(frames), 0 if frames is None else frames.stride(0), _ptr(fid),
+            _ptr(gout), X, Y, Z, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B, _ptr(recon), _ptr(grad),
+            _ptr(loss), _ptr(frame_loss), _ptr(reg), workspace.data_ptr(),
+            workspace.numel() * workspace.element_size(), _stream())
+    _lib.check(rc, "dnmf_warp_recon_grad")
     return {"recon": recon, "loss": loss, "frame_loss": frame_loss, "reg": reg, "workspace": workspace}
 
 
@@ -122,10 +144,12 @@ def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_strid
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
     r = torch.empty((B, K), dtype=torch.float32, device=dev)
-    _lib.check(lib.dnmf_warp_gram_rhs(
-        Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, beta.data_ptr(), beta.shape[2], _ptr(tt), B,
-        frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
-        workspace.numel() * workspace.element_size(), _stream()), "dnmf_warp_gram_rhs")
+    with _timed("warp_gram_rhs"):
+        rc = lib.dnmf_warp_gram_rhs(
+            Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, beta.data_ptr(), beta.shape[2], _ptr(tt), B,
+            frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
+            workspace.numel() * workspace.element_size(), _stream())
+    _lib.check(rc, "dnmf_warp_gram_rhs")
     return G, r, workspace
 
 
@@ -151,3 +175,24 @@ def mu_temporal_step(G, r, Cin, Cout, gamma: float, c_left=None, c_right=None):
                                                  Cin.stride(0), K, T, float(gamma), _ptr(c_left), _ptr(c_right),
                                                  _stream()), "dnmf_mu_temporal_step")
     return Cout
+
+
+def render_frames(positions, traces, sz, shape_std, t0=0, T=None, out=None):
+    """Simulator render loop on the GPU: frames t0..t0+T-1 of the video as (T,P) fp32."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    pos = _f32(positions, "positions")
+    if not (traces.is_cuda and traces.dtype == torch.float64 and traces.is_contiguous()):
+        raise ValueError("render_frames: traces must be a contiguous float64 CUDA tensor")
+    K, _, T_total = pos.shape
+    T = T_total - t0 if T is None else int(T)
+    if out is None:
+        out = torch.empty((T, P), dtype=torch.float32, device=pos.device)
+    lib = _lib.load()
+    amp = float(traces.max())
+    for s in range(0, T, 32768):
+        n = min(32768, T - s)
+        _lib.check(lib.dnmf_render_frames(pos.data_ptr(), traces.data_ptr(), K, T_total, t0 + s, n, X, Y, Z,
+                                          float(shape_std), amp, out[s:].data_ptr(), out.stride(0), _stream()),
+                   "dnmf_render_frames")
+    return out

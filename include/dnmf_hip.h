@@ -122,6 +122,15 @@ int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, dou
                           int T, double gamma, const double *c_left, const double *c_right,
                           dnmf_stream_t stream);
 
+/* ---- synthetic input: the render loop of the simulator ------------------------------------------------
+ * WUtils/Simulator.py:66-73 (generate_video) with simulate_cell (:197-212): frame t0+t receives, neuron by
+ * neuron in index order, fp32(traces[k,t] * exp(-|v - positions[k,:,t]|^2 / (2 shape_std))) added in fp32.
+ *   positions (K,3,T_total) fp32, traces (K,T_total) fp64, out (T,P) fp32 row stride ldo (frames t0..t0+T-1)
+ *   amp_max >= max(traces): bounds the window outside which a term is exactly 0 after the fp32 cast */
+int dnmf_render_frames(const float *positions, const double *traces, int K, int T_total, int t0, int T, int X,
+                       int Y, int Z, double shape_std, double amp_max, float *out, long ldo,
+                       dnmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,3 +266,28 @@ def test_full_size_properties(M):
     assert torch.equal(G, G.transpose(1, 2))
     C = M._mu_temporal(G, r, torch.rand(K, T, device="cuda"), None, 50)
     assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
+
+
+def test_G8_device_simulator(M):
+    """The GPU render loop + normalisation against the reference video (noise passed in: the reference
+    draws it from the CPU generator)."""
+    from dnmf_amd.WUtils import Simulator as S
+    g = golden("G8_simulator")
+    par = {"sigma": [5, 5, .01], "ls": [10, 10, 10]}
+    X, Y, Z = g["sz"].tolist()
+    for snr, key in ((-120, "video"), (-20, "video_noisy")):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        noise = np.sqrt(10 ** (snr / 10)) * torch.distributions.normal.Normal(0, 1).sample(np.array([X, Y, Z, 6]))
+        np.random.seed(0)
+        frames, positions, traces = S.generate_video_resident(3, 6, [X, Y, Z], 3, .2, snr, par, noise=noise)
+        got = frames.view(6, X, Y, Z).permute(1, 2, 3, 0).cpu().numpy()
+        np.testing.assert_allclose(got, g[key], rtol=5e-6, atol=1e-9)
+        np.testing.assert_array_equal(traces, g["traces"])
+    # a slice of the T axis is the same frames
+    np.random.seed(0)
+    part, _, _ = S.generate_video_resident(3, 6, [X, Y, Z], 3, .2, -120, par, noise=torch.zeros(6, X * Y * Z), t0=2, t1=5)
+    np.random.seed(0)
+    full, _, _ = S.generate_video_resident(3, 6, [X, Y, Z], 3, .2, -120, par, noise=torch.zeros(6, X * Y * Z))
+    # different normalisers (slice-local vs global) -> compare up to scale
+    np.testing.assert_allclose((part / part.max()).cpu().numpy(), (full[2:5] / full[2:5].max()).cpu().numpy(), rtol=1e-5, atol=1e-9)
