@@ -17,8 +17,10 @@
 // (channel l&15 of voxel l>>4), so one k-step (4 voxels) needs NB fragment registers per lane.  The
 // channel <-> (block, lane) assignment is free (a Gram matrix is permutation-equivariant); it is chosen
 // so that a lane's NB values are contiguous runs of its footprint row (16/8/4-byte loads):
-//   blocks 4g..4g+3 -> channels 64g + 4i + (b-4g);  then a pair -> base + 2i + (b-b0);  then base + i.
-// The permutation is undone when the tiles are scattered into G (gram_finish_kernel).
+//   blocks 4g..4g+3 -> channels 64g + 4i + (b-4g);  the R = NB%4 remaining blocks -> base + R*i + (b-b0).
+// The frame rides in channel Kp-1 (= block NB-1, lane slot 15, always a pad column), so A_t^T y is the last
+// row of the same product.  The permutation is undone when the tiles are scattered into G
+// (gram_finish_kernel).
 //
 // Warp.  Coordinates, floors and corner weights are computed once per voxel by one lane (64 voxels per
 // pass), parked in wave-private LDS and re-read as broadcasts by the 16 lanes that share the voxel.
@@ -30,7 +32,8 @@ namespace dnmf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int K3_SS = 64;  // voxels per coordinate pass (one per lane)
 
@@ -38,40 +41,35 @@ template <int NB>
 __host__ __device__ constexpr int chan_of(int b, int i) {
     constexpr int NG4 = NB / 4, R = NB % 4, base = 64 * NG4;
     if (b < 4 * NG4) return 64 * (b / 4) + 4 * i + (b % 4);
-    const int rb = b - 4 * NG4;
-    if (R == 1) return base + i;
-    if (R == 2) return base + 2 * i + rb;
-    return rb < 2 ? base + 2 * i + rb : base + 32 + i;  // R == 3
+    return base + R * i + (b - 4 * NG4);
 }
 
 __host__ __device__ constexpr int tile_index(int NB, int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
 
-// NB fragment values of one footprint row for lane slot i (channel permutation above).
+// NB fragment values of one footprint row for lane slot i (channel permutation above): NB/4 16-byte loads
+// at byte 256 g + 16 i plus one 4*(NB%4)-byte load at byte 256 (NB/4) + 4 (NB%4) i.
 template <int NB>
 struct RowFrag {
     float v[NB];
 };
 
 template <int NB>
-__device__ __forceinline__ RowFrag<NB> load_row(const float *__restrict__ rp, int i) {
-    constexpr int NG4 = NB / 4, R = NB % 4, base = 64 * NG4;
-    RowFrag<NB> f;
+__device__ __forceinline__ void load_row(RowFrag<NB> &f, const char *__restrict__ base, unsigned off_a, unsigned off_b) {
+    constexpr int NG4 = NB / 4, R = NB % 4;
 #pragma unroll
     for (int g = 0; g < NG4; ++g) {
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(rp + 64 * g + 4 * i);
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(base + (size_t)(off_a + 256u * g));
         f.v[4 * g + 0] = t[0], f.v[4 * g + 1] = t[1], f.v[4 * g + 2] = t[2], f.v[4 * g + 3] = t[3];
     }
     if constexpr (R == 1) {
-        f.v[4 * NG4] = rp[base + i];
+        f.v[4 * NG4] = *reinterpret_cast<const float *>(base + (size_t)off_b);
     } else if constexpr (R == 2) {
-        const f32x2 t = *reinterpret_cast<const f32x2 *>(rp + base + 2 * i);
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(base + (size_t)off_b);
         f.v[4 * NG4] = t[0], f.v[4 * NG4 + 1] = t[1];
     } else if constexpr (R == 3) {
-        const f32x2 t = *reinterpret_cast<const f32x2 *>(rp + base + 2 * i);
-        f.v[4 * NG4] = t[0], f.v[4 * NG4 + 1] = t[1];
-        f.v[4 * NG4 + 2] = rp[base + 32 + i];
+        const f32x3 t = *reinterpret_cast<const f32x3 *>(base + (size_t)off_b);
+        f.v[4 * NG4] = t[0], f.v[4 * NG4 + 1] = t[1], f.v[4 * NG4 + 2] = t[2];
     }
-    return f;
 }
 
 struct GramParams {
@@ -92,13 +90,20 @@ struct GramParams {
 };
 
 // NTAP = 4 (Z == 1, bilinear) or 8 (trilinear).  Tap c: dx = c&1, dy = (c>>1)&1, dz = c>>2 (ATen's corner order).
+//
+// Schedule.  A k-step is {request the NTAP rows, blend them into NB fragments, NT MFMAs}.  The three
+// stages of consecutive k-steps overlap inside one wave: while the MFMAs of step k are issued the rows of
+// step k+2 are in flight and the fragments of step k+1 are blended in the issue slots the matrix pipe
+// leaves free (an MFMA holds vector issue for 8 of its 32 cycles).  Two register sets (A/B) alternate, so
+// the loop body is a pair of k-steps.  Voxel records are double-buffered in LDS one pass (64 voxels) ahead.
 template <int NB, int NTAP>
-__global__ __launch_bounds__(256) void warp_gram_kernel(GramParams p) {
+__global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramParams p) {
     constexpr int NT = NB * (NB + 1) / 2;
     constexpr int NQ = NTAP / 4;
-    __shared__ i32x4 s_row[4][NQ][K3_SS];
-    __shared__ f32x4 s_w[4][NQ][K3_SS];
-    __shared__ float s_y[4][K3_SS];
+    constexpr int NG4 = NB / 4, R = NB % 4;
+    __shared__ u32x4 s_row[4][2][NQ][K3_SS];
+    __shared__ f32x4 s_w[4][2][NQ][K3_SS];
+    __shared__ float s_y[4][2][K3_SS];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,20 +112,18 @@ __global__ __launch_bounds__(256) void warp_gram_kernel(GramParams p) {
     const int chunk = (int)(item / p.B);
     const int b = (int)(item - (long)chunk * p.B);
     const int t = p.times ? p.times[b] : b;
-    const float *__restrict__ Ab = p.Apk + (long)b * p.a_frame_stride;
+    const char *__restrict__ Ab = reinterpret_cast<const char *>(p.Apk + (long)b * p.a_frame_stride);
     const float *__restrict__ yb = p.frames + (long)(p.frame_ids ? p.frame_ids[b] : b) * p.ldf;
     const Volume vol = p.vol;
-    const int Kp = p.Kp;
+    const unsigned row_bytes = (unsigned)p.Kp * 4u;
 
     float bt[30];
     load_beta(p.beta, p.T, t, bt);
 
     const int ci = lane & 15;   // channel slot
     const int vq = lane >> 4;   // voxel slot inside a k-step
-    int ysel = -1;              // block whose channel for this lane is the frame column K
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb)
-        if (chan_of<NB>(bb, ci) == p.K) ysel = bb;
+    const unsigned lane_a = 16u * ci, lane_b = 256u * NG4 + 4u * R * ci;
+    const bool ylane = ci == 15;  // (block NB-1, slot 15) = channel Kp-1 carries the frame
 
     f32x4 acc[NT];
 #pragma unroll
@@ -128,91 +131,117 @@ __global__ __launch_bounds__(256) void warp_gram_kernel(GramParams p) {
 
     const long v_begin = (long)chunk * p.chunk_len;
     const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
+    const int nss = (int)((v_end - v_begin + K3_SS - 1) / K3_SS);
+    const int nk = nss * (K3_SS / 4);
 
-    for (long vbase = v_begin; vbase < v_end; vbase += K3_SS) {
-        // ---- coordinate pass: lane -> voxel vbase + lane ------------------------------------------
-        {
-            const long v = vbase + lane;
-            int rows[NTAP];
-            float w[NTAP];
-            float yv = 0.0f;
+    // coordinate pass s: lane -> voxel v_begin + 64 s + lane, record into LDS buffer s & 1
+    auto coord_pass = [&](int s) {
+        const long v = v_begin + (long)s * K3_SS + lane;
+        unsigned rows[NTAP];
+        float w[NTAP];
+        float yv = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NTAP; ++c) rows[c] = 0, w[c] = 0.0f;
-            if (v < v_end) {
-                int x, y, z;
-                voxel_xyz(v, vol, x, y, z);
-                const Sample s = make_sample(bt, vol, x, y, z);
+        for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
+        if (v < v_end) {
+            int x, y, z;
+            voxel_xyz(v, vol, x, y, z);
+            const Sample sm = make_sample(bt, vol, x, y, z);
 #pragma unroll
-                for (int c = 0; c < NTAP; ++c) {
-                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                    const int cx = s.x0 + dx, cy = s.y0 + dy, cz = s.z0 + dz;
-                    const bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z);
-                    const float wc = __fmul_rn(__fmul_rn(dx ? s.wx1 : s.wx0, dy ? s.wy1 : s.wy0), dz ? s.wz1 : s.wz0);
-                    w[c] = ok ? wc : 0.0f;
-                    rows[c] = ok ? ((cx * vol.Y + cy) * vol.Z + cz) * Kp : 0;
-                }
-                yv = yb[v];
+            for (int c = 0; c < NTAP; ++c) {
+                const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
+                const bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z);
+                const float wc = __fmul_rn(__fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0), dz ? sm.wz1 : sm.wz0);
+                w[c] = ok ? wc : 0.0f;
+                rows[c] = ok ? (unsigned)((cx * vol.Y + cy) * vol.Z + cz) * row_bytes : 0u;
             }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                s_row[wave][q][lane] = i32x4{rows[4 * q], rows[4 * q + 1], rows[4 * q + 2], rows[4 * q + 3]};
-                s_w[wave][q][lane] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-            }
-            s_y[wave][lane] = yv;
+            yv = yb[v];
         }
-        // LDS traffic of one wave is processed in order; only the compiler has to be kept from reordering
+        const int buf = s & 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            s_row[wave][buf][q][lane] = u32x4{rows[4 * q], rows[4 * q + 1], rows[4 * q + 2], rows[4 * q + 3]};
+            s_w[wave][buf][q][lane] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        }
+        s_y[wave][buf][lane] = yv;
+    };
+    // LDS traffic of one wave is processed in order; only the compiler has to be kept from reordering
+    auto wave_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
-        // ---- 16 k-steps of 4 voxels ------------------------------------------------------------------
-        // Software pipeline, distance one: the footprint rows of k-step ks+1 are requested before the
-        // MFMAs of k-step ks are issued, so their latency hides behind 28 x 32 matrix-core cycles.
+    struct Stage {
         RowFrag<NB> raw[NTAP];
-        f32x4 wcur[NQ];
-        float ycur;
-        auto issue = [&](int ks) {
-            const int vi = ks * 4 + vq;
+        f32x4 w[NQ];
+        float y;
+    };
+    auto issue = [&](int kk, Stage &st) {
+        const int kc = kk < nk ? kk : nk - 1;  // past the end: re-read the last step (result unused)
+        const int buf = (kc >> 4) & 1;
+        const int vi = (kc & 15) * 4 + vq;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const i32x4 rr = s_row[wave][q][vi];
-                wcur[q] = s_w[wave][q][vi];
+        for (int q = 0; q < NQ; ++q) {
+            const u32x4 rr = s_row[wave][buf][q][vi];
+            st.w[q] = s_w[wave][buf][q][vi];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) raw[4 * q + e] = load_row<NB>(Ab + rr[e], ci);
-            }
-            ycur = s_y[wave][vi];
-        };
-        issue(0);
-#pragma unroll 2
-        for (int ks = 0; ks < K3_SS / 4; ++ks) {
-            // keep the consumer of the previous request from being hoisted above these MFMAs' issue
-            // point: it would wait for loads that were requested a few instructions earlier
-            __builtin_amdgcn_sched_barrier(0);
-            float frag[NB];
+            for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rr[e] + lane_a, rr[e] + lane_b);
+        }
+        st.y = s_y[wave][buf][vi];
+    };
+    auto blend = [&](const Stage &st, float (&frag)[NB]) {
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) frag[bb] = raw[0].v[bb] * wcur[0][0];
+        for (int bb = 0; bb < NB; ++bb) frag[bb] = st.raw[0].v[bb] * st.w[0][0];
 #pragma unroll
-            for (int c = 1; c < NTAP; ++c) {
+        for (int c = 1; c < NTAP; ++c) {
 #pragma unroll
-                for (int bb = 0; bb < NB; ++bb) frag[bb] = fmaf(raw[c].v[bb], wcur[c >> 2][c & 3], frag[bb]);
-            }
+            for (int bb = 0; bb < NB; ++bb) frag[bb] = fmaf(st.raw[c].v[bb], st.w[c >> 2][c & 3], frag[bb]);
+        }
+        frag[NB - 1] = ylane ? st.y : frag[NB - 1];
+    };
+    auto mfmas = [&](const float (&frag)[NB]) {
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) frag[bb] = (bb == ysel) ? ycur : frag[bb];
-            if (ks + 1 < K3_SS / 4) issue(ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
-            for (int bi = 0; bi < NB; ++bi) {
-#pragma unroll
-                for (int bj = bi; bj < NB; ++bj) {
-                    const int idx = tile_index(NB, bi, bj);
-                    acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[bi], frag[bj], acc[idx], 0, 0, 0);
-                }
+            for (int bj = bi; bj < NB; ++bj) {
+                const int idx = tile_index(NB, bi, bj);
+                acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[bi], frag[bj], acc[idx], 0, 0, 0);
             }
         }
-        // the next coordinate pass overwrites the records: keep it behind this pass's reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // one k-step: request the rows of step kk_req, then blend the fragments of the NEXT step (rows requested
+    // one step ago) in the shadow of the MFMAs of the CURRENT step, one vector instruction per MFMA gap
+    auto step = [&](int kk_req, Stage &st_req, const Stage &st_next, float (&f_next)[NB], const float (&f_cur)[NB]) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kk_req, st_req);
+        __builtin_amdgcn_sched_barrier(0);
+        blend(st_next, f_next);
+        mfmas(f_cur);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, NTAP / 4, 0);  // VALU of the blend
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    Stage sa, sb;
+    float fa[NB], fb[NB];
+    coord_pass(0);
+    wave_fence();
+    issue(0, sa);
+    issue(1, sb);
+    blend(sa, fa);
+    for (int s = 0; s < nss; ++s) {
+        if (s + 1 < nss) coord_pass(s + 1);
+        wave_fence();
+#pragma unroll 1
+        for (int kk = s * (K3_SS / 4); kk < (s + 1) * (K3_SS / 4); kk += 2) {
+            step(kk + 2, sa, sb, fb, fa);
+            step(kk + 3, sb, sa, fa, fb);
+        }
     }
 
     f32x4 *out = reinterpret_cast<f32x4 *>(p.slab) + (((long)b * p.nchunks + chunk) * NT) * 64 + lane;
@@ -241,12 +270,13 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
             float s = 0.0f;
             for (int c = 0; c < nchunks; ++c) s += src[(long)c * NT * 256];
             const int k = chan_of<NB>(bi, i), l = chan_of<NB>(bj, j);
+            constexpr int YC = 16 * NB - 1;  // channel that carries the frame
             if (k < K && l < K) {
                 Gb[(long)k * K + l] = s;
                 Gb[(long)l * K + k] = s;
-            } else if (k < K && l == K) {
+            } else if (k < K && l == YC) {
                 rb[k] = s;
-            } else if (k == K && l < K) {
+            } else if (k == YC && l < K) {
                 rb[l] = s;
             }
         }
@@ -300,8 +330,8 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
     p.vol = make_volume(X, Y, Z);
     DNMF_REQUIRE(ldf >= p.vol.P && a_frame_stride >= 0, DNMF_E_SHAPE, "dnmf_warp_gram_rhs: ldf=%ld < P=%ld", ldf,
                  p.vol.P);
-    DNMF_REQUIRE(p.vol.P * Kp < (1L << 31), DNMF_E_UNSUPPORTED,
-                 "dnmf_warp_gram_rhs: P*Kp=%ld does not fit 32-bit row offsets", p.vol.P * Kp);
+    DNMF_REQUIRE(p.vol.P * Kp < (1L << 30), DNMF_E_UNSUPPORTED,
+                 "dnmf_warp_gram_rhs: P*Kp=%ld does not fit 32-bit byte offsets", p.vol.P * Kp);
     DNMF_REQUIRE((reinterpret_cast<size_t>(Apk) & 15) == 0 && (a_frame_stride % 4) == 0 &&
                      (reinterpret_cast<size_t>(workspace) & 15) == 0,
                  DNMF_E_SHAPE, "dnmf_warp_gram_rhs: Apk / workspace must be 16-byte aligned");

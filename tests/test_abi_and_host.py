@@ -72,21 +72,16 @@ def test_product_has_no_cpu_fallback():
 def chan_of(NB, b, i):
     """Python mirror of csrc/warp_gram_rhs.hip:chan_of -- the channel held by lane slot i for block b."""
     ng4, r = divmod(NB, 4)
-    base = 64 * ng4
     if b < 4 * ng4:
         return 64 * (b // 4) + 4 * i + (b % 4)
-    rb = b - 4 * ng4
-    if r == 1:
-        return base + i
-    if r == 2:
-        return base + 2 * i + rb
-    return base + 2 * i + rb if rb < 2 else base + 32 + i
+    return 64 * ng4 + r * i + (b - 4 * ng4)
 
 
 @pytest.mark.parametrize("NB", range(1, 9))
 def test_gram_channel_permutation_is_a_bijection(NB):
     seen = sorted(chan_of(NB, b, i) for b in range(NB) for i in range(16))
     assert seen == list(range(16 * NB))
+    assert chan_of(NB, NB - 1, 15) == 16 * NB - 1   # the frame column is the last pad channel
 
 
 def test_simulator_reproduces_reference_video():
