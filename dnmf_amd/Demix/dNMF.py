@@ -179,6 +179,9 @@ class DeformableNMF:
             self.D = None
         self._ws_k2 = None
         self._ws_k3 = None
+        # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
+        # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
+        self.fused_motion = True
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
     @staticmethod
@@ -272,10 +275,14 @@ class DeformableNMF:
         S_all = self._recon_cache()
         Cdev = None if S_all is not None else self.C.to(device, torch.float32).contiguous()
         resident = isinstance(dataloader, ResidentLoader)
+        fused = resident and S_all is not None and self._fusable(optimizer)
         for epoch in range(1, epochs + 1):
             if self.verbose:
                 print('Epoch ' + str(epoch))
             fp.train()
+            if fused:
+                self._motion_epoch(dataloader, optimizer, S_all)
+                continue
             for batch_idx, data in enumerate(dataloader.iter_indices() if resident else dataloader):
                 optimizer.zero_grad()
                 times = data if resident else data[1]
@@ -298,6 +305,59 @@ class DeformableNMF:
                 if want:
                     print('Recon: ' + str(out["loss"][0]))
                     print('Reg: ' + str(out["reg"]))
+
+    def _fusable(self, optimizer):
+        """True when ``optimizer`` is exactly the reference demo's: torch.optim.Adam([fp.beta]) without
+        amsgrad / weight decay / maximize, so that its update can be evaluated per column in closed form."""
+        if not self.fused_motion or type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        if len(g['params']) != 1 or g['params'][0] is not self.fp.beta:
+            return False
+        return not (g.get('amsgrad') or g.get('maximize') or g.get('weight_decay', 0) != 0 or g.get('capturable')
+                    or g.get('differentiable') or g.get('fused') or g.get('decoupled_weight_decay'))
+
+    def _motion_epoch(self, loader, optimizer, S_all):
+        """One epoch of mini-batch Adam steps in four launches (dnmf_adam_epoch phase 0, K2 over all frames,
+        phase 1).  The optimiser's own state tensors are read and written, so the caller's optimiser stays
+        valid and a later un-fused step continues from it."""
+        fp, beta = self.fp, self.fp.beta
+        g = optimizer.param_groups[0]
+        state = optimizer.state[beta]
+        if len(state) == 0:  # what torch.optim.Adam._init_group creates on the first step()
+            state['step'] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+            state['exp_avg'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
+            state['exp_avg_sq'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
+        batches = list(loader.iter_indices())
+        n = len(batches)
+        sizes = torch.tensor([b.numel() for b in batches])
+        order = torch.cat(batches)
+        frame_step = torch.full((fp.T,), -1, dtype=torch.int32, device=device)
+        frame_step[order.long()] = torch.repeat_interleave(torch.arange(n, dtype=torch.int32), sizes).to(device)
+        step0 = int(state['step'])
+        args = (step0, frame_step, n, g['lr'], g['betas'], g['eps'])
+        with torch.no_grad():
+            ops.adam_epoch(beta, None, state['exp_avg'], state['exp_avg_sq'], *args, phase=0)
+            grad = torch.zeros_like(beta)
+            bs = int(sizes[0])
+            n_full = int((sizes == bs).sum()) * bs if bool((sizes[:-1] == bs).all()) else 0
+            groups = [(order[:n_full], bs)] if n_full else []
+            groups += [(b, b.numel()) for b in (batches if not n_full else batches[n_full // bs:])]
+            outs = []
+            for idx, nf in groups:
+                out = ops.warp_recon_grad(S_all, idx, loader.frames_2d(), idx, fp.sz_list, beta, idx, grad=grad,
+                                          want_loss=self.verbose, want_reg=self.verbose, workspace=self._ws_k2,
+                                          norm_frames=nf)
+                self._ws_k2 = out["workspace"]
+                outs.append((idx, nf, out))
+            ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1)
+        state['step'] += n
+        beta.grad = grad
+        if self.verbose:
+            idx, nf, out = outs[0]
+            for j in range(0, idx.numel() // nf, 10):
+                print('Recon: ' + str(out["frame_loss"][j * nf:(j + 1) * nf].sum()))
+                print('Reg: ' + str(out["reg"][j * nf:(j + 1) * nf]))
 
     def fit(self, dataloader, testloader, optimizer, batch_size, outer=5, gamma=1, epochs=10, gamma_c=0, iter_c=50):
         """Convenience wrapper of the loop ``demo.py:44-46`` writes out (not part of the reference)."""

@@ -22,13 +22,14 @@ SIGNATURES = {
     "dnmf_warp_gather": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "dnmf_recon_image": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dnmf_warp_recon_grad_workspace": (_sz, [_l, _i]),
-    "dnmf_warp_recon_grad": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
+    "dnmf_warp_recon_grad": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _sz, _vp]),
     "dnmf_warp_gram_rhs_workspace": (_sz, [_l, _i, _i]),
     "dnmf_warp_gram_rhs": (_i, [_vp, _i, _i, _l, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz,
                                 _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
+    "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _i, _d, _d, _d, _d, _i, _vp]),
     "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
 }
 

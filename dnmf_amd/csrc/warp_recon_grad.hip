@@ -126,14 +126,14 @@ __device__ float log_det_jac_dev(const float *b, float x, float y, float z) {
 // One block per frame: ordered sum of the per-block partials, scale, add into grad, per-frame loss, reg.
 __global__ __launch_bounds__(64) void warp_recon_grad_finish_kernel(const float *__restrict__ partial, int nblk,
                                                                     Volume vol, const float *__restrict__ beta, int T,
-                                                                    const int *__restrict__ times, int B,
+                                                                    const int *__restrict__ times, int norm_frames,
                                                                     float grad_scale, float *__restrict__ grad,
                                                                     float *__restrict__ frame_loss,
                                                                     float *__restrict__ reg) {
     const int b = blockIdx.x;
     const int t = times[b];
     const int j = threadIdx.x;
-    const float inv_n = 1.0f / ((float)B * (float)vol.P);
+    const float inv_n = 1.0f / ((float)norm_frames * (float)vol.P);
     if (j < 31) {
         const float *src = partial + (long)b * nblk * K2_NACC + j;
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four interleaved chains, fixed order
@@ -181,7 +181,7 @@ size_t dnmf_warp_recon_grad_workspace(long P, int B) {
 
 int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
                          const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta, int T,
-                         const int *times, int B, float *recon, float *grad, float *loss, float *frame_loss, float *reg,
+                         const int *times, int B, int norm_frames, float *recon, float *grad, float *loss, float *frame_loss, float *reg,
                          void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(S && (frames || gout) && beta && times && workspace, DNMF_E_NULL,
@@ -200,9 +200,10 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(warp_recon_grad_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds, s_ids,
                        frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
-    const float grad_scale = gout ? 1.0f : 2.0f / ((float)B * (float)vol.P);
+    if (norm_frames <= 0) norm_frames = B;
+    const float grad_scale = gout ? 1.0f : 2.0f / ((float)norm_frames * (float)vol.P);
     hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T,
-                       times, B, grad_scale, grad, (loss || frame_loss) ? fl : nullptr, reg);
+                       times, norm_frames, grad_scale, grad, (loss || frame_loss) ? fl : nullptr, reg);
     if (loss) hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(64), 0, st, fl, B, loss);
     return check_launch("dnmf_warp_recon_grad");
 }

@@ -94,7 +94,7 @@ def recon_image(Apk: torch.Tensor, K: int, C: torch.Tensor, times, out: torch.Te
 
 
 def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gout=None, want_recon=False,
-                    want_loss=True, want_reg=True, workspace=None):
+                    want_loss=True, want_reg=True, workspace=None, norm_frames=0):
     """K2.  S (>=B, lds) recon images, frames (>=B, ldf) or None with gout (B,P).
     Returns dict(recon, loss, frame_loss, reg); ``grad`` (10,3,T) is incremented in place."""
     X, Y, Z = (int(s) for s in sz)
@@ -120,7 +120,8 @@ def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gou
     with _timed("warp_recon_grad"):
         rc = lib.dnmf_warp_recon_grad(
             S.data_ptr(), S.stride(0), _ptr(sid), _ptr(frames), 0 if frames is None else frames.stride(0), _ptr(fid),
-            _ptr(gout), X, Y, Z, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B, _ptr(recon), _ptr(grad),
+            _ptr(gout), X, Y, Z, beta.data_ptr(), beta.shape[2], tt.data_ptr(), B, int(norm_frames), _ptr(recon),
+            _ptr(grad),
             _ptr(loss), _ptr(frame_loss), _ptr(reg), workspace.data_ptr(),
             workspace.numel() * workspace.element_size(), _stream())
     _lib.check(rc, "dnmf_warp_recon_grad")
@@ -196,3 +197,16 @@ def render_frames(positions, traces, sz, shape_std, t0=0, T=None, out=None):
                                           float(shape_std), amp, out[s:].data_ptr(), out.stride(0), _stream()),
                    "dnmf_render_frames")
     return out
+
+
+def adam_epoch(beta, grad, exp_avg, exp_avg_sq, step0, frame_step, nsteps, lr, betas, eps, phase):
+    """One phase of the per-column Adam epoch (see include/dnmf_hip.h); tensors updated in place."""
+    for t, n in ((beta, "beta"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _f32(t, n)
+    if grad is not None:
+        _f32(grad, "grad")
+    fs = _i32(frame_step, beta.device)
+    _lib.check(_lib.load().dnmf_adam_epoch(beta.data_ptr(), _ptr(grad), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                           beta.shape[2], int(step0), fs.data_ptr(), int(nsteps), float(lr),
+                                           float(betas[0]), float(betas[1]), float(eps), int(phase), _stream()),
+               "dnmf_adam_epoch")

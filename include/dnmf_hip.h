@@ -79,13 +79,15 @@ int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, lo
  *   recon   (B,P) A_tC or NULL
  *   grad    (10,3,T): columns times[b] are INCREMENTED by the gradient (autograd .grad semantics);
  *           times must not contain duplicates
- *   loss    (1) mean squared error of the batch;  frame_loss (B) per-frame sum of squares / (B*P) or NULL
+ *   norm_frames  number of frames the mean of the loss runs over (0 -> B): lets one launch evaluate many
+ *           mini-batches of norm_frames frames each
+ *   loss    (1) sum over b of frame_loss;  frame_loss (B) per-frame sum of squares / (norm_frames*P) or NULL
  *   reg     (B) or NULL
  *   workspace: dnmf_warp_recon_grad_workspace(P,B) bytes */
 size_t dnmf_warp_recon_grad_workspace(long P, int B);
 int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
                          const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta,
-                         int T, const int *times, int B, float *recon, float *grad, float *loss,
+                         int T, const int *times, int B, int norm_frames, float *recon, float *grad, float *loss,
                          float *frame_loss, float *reg, void *workspace, size_t workspace_bytes,
                          dnmf_stream_t stream);
 
@@ -121,6 +123,19 @@ int dnmf_mu_temporal(const float *G, const float *r, float *C, long ldc, int K, 
 int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K,
                           int T, double gamma, const double *c_left, const double *c_right,
                           dnmf_stream_t stream);
+
+/* ---- Adam on beta for one epoch of mini-batches ------------------------------------------------------
+ * update_motion steps the caller's torch.optim.Adam once per mini-batch on the whole (10,3,T) tensor
+ * (Demix/dNMF.py:186-191; optimiser built at demo.py:42): columns outside the mini-batch get a zero gradient
+ * but still move once they have moment history.  Columns are independent, so an epoch of `nsteps` steps in
+ * which frame t belongs to mini-batch frame_step[t] (0-based, <0 = none) is evaluated per column:
+ *   phase 0: the frame_step[t] zero-gradient steps before its mini-batch (then run K2 on all frames),
+ *   phase 1: the step with grad[:, :, t] and the zero-gradient steps after it.
+ * beta, exp_avg, exp_avg_sq (10,3,T) are the optimiser's own tensors, updated in place; step0 = steps taken
+ * before this epoch.  Same arithmetic as torch.optim.Adam (amsgrad off, weight_decay 0, maximize off). */
+int dnmf_adam_epoch(float *beta, const float *grad, float *exp_avg, float *exp_avg_sq, int T, long step0,
+                    const int *frame_step, int nsteps, double lr, double beta1, double beta2, double eps,
+                    int phase, dnmf_stream_t stream);
 
 /* ---- synthetic input: the render loop of the simulator ------------------------------------------------
  * WUtils/Simulator.py:66-73 (generate_video) with simulate_cell (:197-212): frame t0+t receives, neuron by

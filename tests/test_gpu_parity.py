@@ -291,3 +291,41 @@ def test_G8_device_simulator(M):
     full, _, _ = S.generate_video_resident(3, 6, [X, Y, Z], 3, .2, -120, par, noise=torch.zeros(6, X * Y * Z))
     # different normalisers (slice-local vs global) -> compare up to scale
     np.testing.assert_allclose((part / part.max()).cpu().numpy(), (full[2:5] / full[2:5].max()).cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("T,bs", [(16, 4), (14, 4)])
+def test_fused_motion_epoch_equals_stepwise_adam(M, O, T, bs):
+    """The per-column evaluation of an epoch of Adam steps (dnmf_adam_epoch + one K2 launch) against
+    torch.optim.Adam stepped mini-batch by mini-batch, over several shuffled epochs (moment history, coasting,
+    ragged last batch)."""
+    torch.manual_seed(3)
+    rng = np.random.RandomState(3)
+    sz, K = [24, 20, 2], 6
+    pos = rng.rand(K, 3) * np.array(sz)
+    frames = torch.rand(T, sz[0] * sz[1] * sz[2], device="cuda")
+    C0 = torch.rand(K, T)
+    # start off the identity: from the identity the first Adam step moves every coefficient by exactly +-lr,
+    # which puts whole curves of voxels exactly ON the source lattice, where the gradient of the trilinear
+    # gather is discontinuous and one ulp in beta decides (true of the reference as well)
+    jitter = (torch.randn(10, 3, T) * torch.tensor([0.3, 3e-3, 3e-3, 3e-3, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4])[:, None, None])
+    res = []
+    for fused in (False, True):
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+        dn.verbose, dn.fused_motion = False, fused
+        dn.C = C0.to("cuda")
+        with torch.no_grad():
+            dn.fp.beta += jitter.to("cuda")
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+        loader = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=torch.Generator().manual_seed(5))
+        dn.update_motion(loader, opt, gamma=1, epochs=3)
+        dn.update_motion(loader, opt, gamma=1, epochs=2)
+        st = opt.state[dn.fp.beta]
+        res.append((dn.fp.beta.detach().cpu().numpy(), st["exp_avg"].cpu().numpy(), st["exp_avg_sq"].cpu().numpy(),
+                    float(st["step"])))
+    ident = O.identity_beta(T) + jitter.numpy()
+    (b0, m0, v0, s0), (b1, m1, v1, s1) = res
+    assert s0 == s1 == 5 * ((T + bs - 1) // bs)
+    disp = np.abs(b0 - ident).max()
+    np.testing.assert_allclose(b1 - ident, b0 - ident, rtol=0, atol=2e-4 * disp)
+    np.testing.assert_allclose(m1, m0, rtol=1e-3, atol=1e-5 * np.abs(m0).max())
+    np.testing.assert_allclose(v1, v0, rtol=1e-3, atol=1e-5 * np.abs(v0).max())
