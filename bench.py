@@ -115,8 +115,10 @@ def main():
     dn = M.DeformableNMF(torch.tensor(sz), K, T_loc, positions=positions0)
     dn.verbose = False
     opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
-    gen = torch.Generator().manual_seed(1234 + rank)
-    train = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=gen)
+    # every rank draws the SAME global mini-batch order and keeps its own frames: the optimiser-step sequence
+    # is the single-process one for the 4000*N-frame video (dnmf_amd/sharding.py)
+    gen = torch.Generator().manual_seed(1234)
+    train = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=gen, t0=rank * T_loc, T_total=T_total)
     test = M.ResidentLoader(frames, sz, bs, shuffle=False)
 
     def step():

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import Dataset
 
-from .. import ops
+from .. import ops, sharding
 from ..WUtils import Simulator
 
 device = 'cuda'
@@ -283,28 +283,41 @@ class DeformableNMF:
             if fused:
                 self._motion_epoch(dataloader, optimizer, S_all)
                 continue
-            for batch_idx, data in enumerate(dataloader.iter_indices() if resident else dataloader):
+            for batch_idx, (times, frames, frame_ids, norm) in enumerate(self._iter_batches(dataloader, resident)):
                 optimizer.zero_grad()
-                times = data if resident else data[1]
-                times = torch.as_tensor(times).to(device, torch.int32).reshape(-1)
                 if beta.grad is None:
                     beta.grad = torch.zeros_like(beta)
-                if resident:
-                    frames, frame_ids = dataloader.frames_2d(), times
-                else:
-                    frames, frame_ids = data[0].to(device, torch.float32).reshape(times.numel(), -1), None
+                if times.numel() == 0:      # sharded: this global mini-batch has no frame here; still a step
+                    optimizer.step()
+                    continue
                 if S_all is not None:
                     S, s_ids = S_all, times
                 else:
                     S, s_ids = ops.recon_image(fp.packed_footprints(), fp.K, Cdev, times), None
                 want = self.verbose and batch_idx % 10 == 0
                 out = ops.warp_recon_grad(S, s_ids, frames, frame_ids, fp.sz_list, beta.detach(), times,
-                                          grad=beta.grad, want_loss=want, want_reg=want, workspace=self._ws_k2)
+                                          grad=beta.grad, want_loss=want, want_reg=want, workspace=self._ws_k2,
+                                          norm_frames=norm)
                 self._ws_k2 = out["workspace"]
                 optimizer.step()
                 if want:
                     print('Recon: ' + str(out["loss"][0]))
                     print('Reg: ' + str(out["reg"]))
+
+    @staticmethod
+    def _iter_batches(dataloader, resident):
+        """(frame indices int32 on the GPU, frames (B,P) or the resident (T,P) rows, row ids or None, frames the
+        loss mean runs over) for every mini-batch of one epoch."""
+        if resident:
+            plan = dataloader.epoch_plan()
+            for j, b in enumerate(plan.batches):
+                size = min(dataloader.batch_size, dataloader.T_total - j * dataloader.batch_size)
+                idx = b.to(device, torch.int32)
+                yield idx, dataloader.frames_2d(), idx, size
+        else:
+            for data in dataloader:
+                times = torch.as_tensor(data[1]).to(device, torch.int32).reshape(-1)
+                yield times, data[0].to(device, torch.float32).reshape(times.numel(), -1), None, 0
 
     def _fusable(self, optimizer):
         """True when ``optimizer`` is exactly the reference demo's: torch.optim.Adam([fp.beta]) without
@@ -328,23 +341,18 @@ class DeformableNMF:
             state['step'] = torch.tensor(0.0, dtype=torch.get_default_dtype())
             state['exp_avg'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
             state['exp_avg_sq'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
-        batches = list(loader.iter_indices())
-        n = len(batches)
-        sizes = torch.tensor([b.numel() for b in batches])
-        order = torch.cat(batches)
-        frame_step = torch.full((fp.T,), -1, dtype=torch.int32, device=device)
-        frame_step[order.long()] = torch.repeat_interleave(torch.arange(n, dtype=torch.int32), sizes).to(device)
+        plan = loader.epoch_plan()
+        n = plan.nsteps
         step0 = int(state['step'])
-        args = (step0, frame_step, n, g['lr'], g['betas'], g['eps'])
+        args = (step0, plan.frame_step.to(device), n, g['lr'], g['betas'], g['eps'])
         with torch.no_grad():
             ops.adam_epoch(beta, None, state['exp_avg'], state['exp_avg_sq'], *args, phase=0)
             grad = torch.zeros_like(beta)
-            bs = int(sizes[0])
-            n_full = int((sizes == bs).sum()) * bs if bool((sizes[:-1] == bs).all()) else 0
-            groups = [(order[:n_full], bs)] if n_full else []
-            groups += [(b, b.numel()) for b in (batches if not n_full else batches[n_full // bs:])]
             outs = []
-            for idx, nf in groups:
+            for idx, nf in plan.groups:
+                if idx.numel() == 0:
+                    continue
+                idx = idx.to(device, torch.int32)
                 out = ops.warp_recon_grad(S_all, idx, loader.frames_2d(), idx, fp.sz_list, beta, idx, grad=grad,
                                           want_loss=self.verbose, want_reg=self.verbose, workspace=self._ws_k2,
                                           norm_frames=nf)
@@ -353,7 +361,7 @@ class DeformableNMF:
             ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1)
         state['step'] += n
         beta.grad = grad
-        if self.verbose:
+        if self.verbose and outs:
             idx, nf, out = outs[0]
             for j in range(0, idx.numel() // nf, 10):
                 print('Recon: ' + str(out["frame_loss"][j * nf:(j + 1) * nf].sum()))
@@ -388,17 +396,22 @@ def _mu_temporal(G, r, C, gamma, iters):
 class ResidentLoader:
     """Iterates mini-batches of a video that already lives on the GPU as (T,P) rows.
 
-    Yields ``(frames (B,X,Y,Z) view, idx int32 tensor)`` like a DataLoader over SimulatedVideoDataset; the
-    fit steps recognise it and index the resident rows directly instead of copying batches (the timed
-    region of bench.py starts with the inputs in HBM).  ``order`` may be a fixed permutation (list of
-    frame indices) or None for 0..T-1; ``shuffle=True`` draws a new permutation per epoch from
-    ``generator``."""
+    Yields ``(frames (B,X,Y,Z), idx int32 tensor)`` like a DataLoader over SimulatedVideoDataset; the fit steps
+    recognise it and index the resident rows directly instead of copying batches (the timed region of bench.py
+    starts with the inputs in HBM).  ``shuffle=True`` draws a new permutation per epoch from ``generator``.
 
-    def __init__(self, frames, sz, batch_size, shuffle=False, generator=None):
+    Sharded use (one process per GPU): ``frames`` holds the block ``[t0, t0+T_local)`` of a ``T_total``-frame
+    video.  Every rank passes a generator with the SAME seed; mini-batches are cut from the global permutation
+    and each rank keeps its own members (``dnmf_amd/sharding.py``), so the optimiser-step sequence is the
+    single-process one."""
+
+    def __init__(self, frames, sz, batch_size, shuffle=False, generator=None, t0=0, T_total=None):
         self.sz = _sz_list(sz)
         self._frames = frames.to(device, torch.float32).reshape(frames.shape[0], -1).contiguous()
         self.batch_size, self.shuffle, self.generator = int(batch_size), shuffle, generator
         self.T = self._frames.shape[0]
+        self.t0 = int(t0)
+        self.T_total = self.T if T_total is None else int(T_total)
 
     def frames_2d(self):
         return self._frames
@@ -407,14 +420,18 @@ class ResidentLoader:
         return torch.arange(self.T, dtype=torch.int32, device=device)
 
     def __len__(self):
-        return (self.T + self.batch_size - 1) // self.batch_size
+        return (self.T_total + self.batch_size - 1) // self.batch_size
+
+    def epoch_plan(self):
+        """Draw this epoch's (global) frame order and return its EpochPlan for the local block."""
+        perm = torch.randperm(self.T_total, generator=self.generator) if self.shuffle else torch.arange(self.T_total)
+        return sharding.plan_epoch(perm, self.batch_size, self.t0, self.t0 + self.T)
 
     def iter_indices(self):
-        """Frame indices of each mini-batch (int32 tensors on the GPU), without touching the frames."""
-        perm = torch.randperm(self.T, generator=self.generator) if self.shuffle else torch.arange(self.T)
-        perm = perm.to(device, torch.int32)
-        for s in range(0, self.T, self.batch_size):
-            yield perm[s:s + self.batch_size]
+        """Local frame indices of each (global) mini-batch, int32 on the GPU; empty for a mini-batch that has no
+        frame in this block."""
+        for b in self.epoch_plan().batches:
+            yield b.to(device, torch.int32)
 
     def __iter__(self):
         for idx in self.iter_indices():

@@ -1,0 +1,58 @@
+"""Host-side logic for sharding the T axis over ranks (one process per GPU).
+
+Frames are independent in both fit steps, so a rank owns a contiguous block of frames together with its columns of
+beta, of the Adam moments and of C; the footprints are replicated.  The only thing ranks must agree on is the
+GLOBAL mini-batch sequence of the motion step: every ``optimizer.step()`` of the reference moves every column of
+beta, so the number of steps a column sees before and after its own mini-batch depends on the global batch order
+(hard part 4).  All ranks therefore draw the same permutation (same seed) and each keeps the
+entries that fall into its block.  Nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+
+def shard_bounds(T_total: int, world: int, rank: int):
+    """Contiguous block [t0, t1) of rank ``rank``; block sizes differ by at most one frame."""
+    base, extra = divmod(int(T_total), int(world))
+    t0 = rank * base + min(rank, extra)
+    return t0, t0 + base + (1 if rank < extra else 0)
+
+
+@dataclass
+class EpochPlan:
+    """One epoch of mini-batches as seen by one shard.
+
+    nsteps       optimiser steps in the epoch (global number of mini-batches)
+    frame_step   (T_local,) int32: 0-based global index of the mini-batch that holds each local frame, -1 if none
+    groups       list of (local frame indices (int64, epoch order), frames per mini-batch): frames whose
+                 mini-batches have the same size share one kernel launch (the mean of the loss runs over that size)
+    batches      per global mini-batch: local frame indices (possibly empty) -- the step-by-step view
+    """
+    nsteps: int
+    frame_step: torch.Tensor
+    groups: list
+    batches: list
+
+
+def plan_epoch(perm: torch.Tensor, batch_size: int, t0: int, t1: int) -> EpochPlan:
+    """Split the global frame order ``perm`` (1-D int64, a permutation of 0..T_total-1 or any visiting order)
+    into mini-batches of ``batch_size`` and keep what belongs to the block [t0, t1)."""
+    perm = perm.to(torch.int64).cpu()
+    n_total = perm.numel()
+    nsteps = (n_total + batch_size - 1) // batch_size
+    step_of_pos = torch.arange(n_total, dtype=torch.int64) // batch_size
+    size_of_step = torch.full((nsteps,), batch_size, dtype=torch.int64)
+    if n_total % batch_size:
+        size_of_step[-1] = n_total % batch_size
+    mine = (perm >= t0) & (perm < t1)
+    local = perm[mine] - t0
+    steps = step_of_pos[mine]
+    frame_step = torch.full((t1 - t0,), -1, dtype=torch.int32)
+    frame_step[local] = steps.to(torch.int32)
+    sizes = size_of_step[steps]
+    groups = [(local[sizes == s], int(s)) for s in sorted(set(sizes.tolist()), reverse=True)]
+    batches = [local[steps == j] for j in range(nsteps)]
+    return EpochPlan(nsteps=nsteps, frame_step=frame_step, groups=groups, batches=batches)

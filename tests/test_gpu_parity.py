@@ -329,3 +329,39 @@ def test_fused_motion_epoch_equals_stepwise_adam(M, O, T, bs):
     np.testing.assert_allclose(b1 - ident, b0 - ident, rtol=0, atol=2e-4 * disp)
     np.testing.assert_allclose(m1, m0, rtol=1e-3, atol=1e-5 * np.abs(m0).max())
     np.testing.assert_allclose(v1, v0, rtol=1e-3, atol=1e-5 * np.abs(v0).max())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_virtual_shards_reproduce_the_single_process_fit(M, fused):
+    """Two T-shards (run one after the other on this GPU, each with its own model, optimiser and loader cut from
+    the same global permutation) give bit-identical beta columns and C columns to the un-sharded fit."""
+    from dnmf_amd import sharding
+    torch.manual_seed(11)
+    rng = np.random.RandomState(11)
+    sz, K, T, bs = [20, 18, 2], 5, 14, 4
+    pos = torch.from_numpy(rng.rand(K, 3) * np.array(sz)).float()
+    frames = torch.rand(T, sz[0] * sz[1] * sz[2], device="cuda")
+    C0 = torch.rand(K, T)
+    jitter = torch.randn(10, 3, T) * torch.tensor([0.3, 3e-3, 3e-3, 3e-3, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4])[:, None, None]
+
+    def run(t0, t1):
+        dn = M.DeformableNMF(torch.tensor(sz), K, t1 - t0, positions=pos)
+        dn.verbose, dn.fused_motion = False, fused
+        dn.C = C0[:, t0:t1].to("cuda").contiguous()
+        with torch.no_grad():
+            dn.fp.beta += jitter[:, :, t0:t1].to("cuda")
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+        train = M.ResidentLoader(frames[t0:t1], sz, bs, shuffle=True, generator=torch.Generator().manual_seed(9),
+                                 t0=t0, T_total=T)
+        test = M.ResidentLoader(frames[t0:t1], sz, bs)
+        for _ in range(2):
+            dn.update_motion(train, opt, gamma=1, epochs=2)
+            dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=7, return_dense=False)
+        return dn.fp.beta.detach().clone(), dn.C.clone()
+
+    beta_full, C_full = run(0, T)
+    for r in range(2):
+        t0, t1 = sharding.shard_bounds(T, 2, r)
+        beta_s, C_s = run(t0, t1)
+        assert torch.equal(beta_s, beta_full[:, :, t0:t1])
+        assert torch.equal(C_s, C_full[:, t0:t1])
