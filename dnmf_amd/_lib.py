@@ -49,6 +49,11 @@ def load():
         raise DnmfHipError(
             f"{LIB_PATH} is missing: build it with `python -m dnmf_amd.build` (hipcc, gfx950). "
             "dnmf_amd has no CPU fallback.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library
+    # is opened so that libdnmf_hip.so binds to the same runtime that owns torch's device pointers and streams;
+    # opened the other way round the process ends up with two runtimes and every launch fails with
+    # hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = stale library
