@@ -25,6 +25,7 @@ struct Volume {
     int X, Y, Z;
     long P;
     float sx1, sy1, sz1;  // (S-1) as fp32, the divisor of Demix/dNMF.py:55 (sz is int64 there)
+    float rcp_yz, rcp_z;  // 1/(Y*Z), 1/Z for the voxel-index split
 };
 
 inline Volume make_volume(int X, int Y, int Z) {
@@ -32,6 +33,7 @@ inline Volume make_volume(int X, int Y, int Z) {
     v.X = X, v.Y = Y, v.Z = Z;
     v.P = (long)X * Y * Z;
     v.sx1 = (float)(X - 1), v.sy1 = (float)(Y - 1), v.sz1 = (float)(Z - 1);
+    v.rcp_yz = 1.0f / ((float)Y * (float)Z), v.rcp_z = 1.0f / (float)Z;
     return v;
 }
 
@@ -81,20 +83,26 @@ __device__ __forceinline__ void axis_weights(float u, int &i0, float &w0, float 
 }
 
 // Full sample for voxel (x,y,z) under beta `b`.  Z == 1: z pinned to 0 (weight 1 on slice 0).
-__device__ __forceinline__ Sample make_sample(const float *b, const Volume &vol, int xi, int yi, int zi) {
-    const float x = (float)xi, y = (float)yi, z = (float)zi;
+// HASZ = false is the Z == 1 specialisation (z == 0 folds the z terms of the polynomial away).
+template <bool HASZ>
+__device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vol, int xi, int yi, int zi) {
+    const float x = (float)xi, y = (float)yi, z = HASZ ? (float)zi : 0.0f;
     Sample s;
     s.ux = unnormalise(normalise(poly_q(b, 0, x, y, z), vol.sx1), vol.sx1);
     s.uy = unnormalise(normalise(poly_q(b, 1, x, y, z), vol.sy1), vol.sy1);
     axis_weights(s.ux, s.x0, s.wx0, s.wx1);
     axis_weights(s.uy, s.y0, s.wy0, s.wy1);
-    if (vol.Z > 1) {
+    if (HASZ) {
         s.uz = unnormalise(normalise(poly_q(b, 2, x, y, z), vol.sz1), vol.sz1);
         axis_weights(s.uz, s.z0, s.wz0, s.wz1);
     } else {
         s.uz = 0.0f, s.z0 = 0, s.wz0 = 1.0f, s.wz1 = 0.0f;
     }
     return s;
+}
+
+__device__ __forceinline__ Sample make_sample(const float *b, const Volume &vol, int xi, int yi, int zi) {
+    return vol.Z > 1 ? make_sample_t<true>(b, vol, xi, yi, zi) : make_sample_t<false>(b, vol, xi, yi, zi);
 }
 
 __device__ __forceinline__ bool in_range(int i, int n) { return (unsigned)i < (unsigned)n; }
@@ -105,13 +113,33 @@ __device__ __forceinline__ void load_beta(const float *__restrict__ beta, int T,
     for (int i = 0; i < 30; ++i) b[i] = beta[(long)i * T + t];
 }
 
+// n / d for 0 <= n < 2^24, d > 0, with rcp = 1/d rounded: the float estimate is off by at most one
+__device__ __forceinline__ int div_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 // voxel index -> (x,y,z), p = (x*Y + y)*Z + z
 __device__ __forceinline__ void voxel_xyz(long p, const Volume &vol, int &x, int &y, int &z) {
     const int yz = vol.Y * vol.Z;
-    x = (int)(p / yz);
-    const int rem = (int)(p - (long)x * yz);
-    y = rem / vol.Z;
-    z = rem - y * vol.Z;
+    if (vol.P <= (1L << 24)) {  // uniform branch: every index is exact in fp32
+        x = div_small((int)p, yz, vol.rcp_yz);
+        const int rem = (int)p - x * yz;
+        if (vol.Z == 1) {
+            y = rem, z = 0;
+        } else {
+            y = div_small(rem, vol.Z, vol.rcp_z);
+            z = rem - y * vol.Z;
+        }
+    } else {
+        x = (int)(p / yz);
+        const int rem = (int)(p - (long)x * yz);
+        y = rem / vol.Z;
+        z = rem - y * vol.Z;
+    }
 }
 
 }  // namespace dnmf

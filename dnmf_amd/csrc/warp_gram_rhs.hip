@@ -145,15 +145,21 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         if (v < v_end) {
             int x, y, z;
             voxel_xyz(v, vol, x, y, z);
-            const Sample sm = make_sample(bt, vol, x, y, z);
+            const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
 #pragma unroll
             for (int c = 0; c < NTAP; ++c) {
                 const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
                 const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
-                const bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z);
-                const float wc = __fmul_rn(__fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0), dz ? sm.wz1 : sm.wz0);
+                bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y);
+                float wc = __fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0);
+                unsigned vox = (unsigned)(cx * vol.Y + cy);
+                if (NTAP == 8) {  // Z == 1: the z weight is exactly 1 and the slice index 0
+                    ok = ok && in_range(cz, vol.Z);
+                    wc = __fmul_rn(wc, dz ? sm.wz1 : sm.wz0);
+                    vox = vox * (unsigned)vol.Z + (unsigned)cz;
+                }
                 w[c] = ok ? wc : 0.0f;
-                rows[c] = ok ? (unsigned)((cx * vol.Y + cy) * vol.Z + cz) * row_bytes : 0u;
+                rows[c] = ok ? vox * row_bytes : 0u;
             }
             yv = yb[v];
         }
@@ -177,18 +183,31 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         f32x4 w[NQ];
         float y;
     };
-    auto issue = [&](int kk, Stage &st) {
+    // voxel record of one k-step, fetched from LDS one step before the rows are requested
+    struct Rec {
+        u32x4 rr[NQ];
+        f32x4 w[NQ];
+        float y;
+    };
+    auto fetch_rec = [&](int kk, Rec &rc) {
         const int kc = kk < nk ? kk : nk - 1;  // past the end: re-read the last step (result unused)
         const int buf = (kc >> 4) & 1;
         const int vi = (kc & 15) * 4 + vq;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const u32x4 rr = s_row[wave][buf][q][vi];
-            st.w[q] = s_w[wave][buf][q][vi];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rr[e] + lane_a, rr[e] + lane_b);
+            rc.rr[q] = s_row[wave][buf][q][vi];
+            rc.w[q] = s_w[wave][buf][q][vi];
         }
-        st.y = s_y[wave][buf][vi];
+        rc.y = s_y[wave][buf][vi];
+    };
+    auto issue = [&](const Rec &rc, Stage &st) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            st.w[q] = rc.w[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rc.rr[q][e] + lane_a, rc.rr[q][e] + lane_b);
+        }
+        st.y = rc.y;
     };
     auto blend = [&](const Stage &st, float (&frag)[NB]) {
 #pragma unroll
@@ -213,9 +232,14 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
 
     // one k-step: request the rows of step kk_req, then blend the fragments of the NEXT step (rows requested
     // one step ago) in the shadow of the MFMAs of the CURRENT step, one vector instruction per MFMA gap
+    // one k-step: request the rows of step kk_req (record already in registers) and fetch the record of
+    // step kk_req+1, then blend the fragments of the NEXT step (rows requested one step ago) in the shadow of
+    // the MFMAs of the CURRENT step, one vector instruction per MFMA gap
+    Rec rec;
     auto step = [&](int kk_req, Stage &st_req, const Stage &st_next, float (&f_next)[NB], const float (&f_cur)[NB]) {
         __builtin_amdgcn_sched_barrier(0);
-        issue(kk_req, st_req);
+        issue(rec, st_req);
+        fetch_rec(kk_req + 1, rec);
         __builtin_amdgcn_sched_barrier(0);
         blend(st_next, f_next);
         mfmas(f_cur);
@@ -231,8 +255,11 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
     float fa[NB], fb[NB];
     coord_pass(0);
     wave_fence();
-    issue(0, sa);
-    issue(1, sb);
+    fetch_rec(0, rec);
+    issue(rec, sa);
+    fetch_rec(1, rec);
+    issue(rec, sb);
+    fetch_rec(2, rec);
     blend(sa, fa);
     for (int s = 0; s < nss; ++s) {
         if (s + 1 < nss) coord_pass(s + 1);
