@@ -144,20 +144,20 @@ class ExponentialFP(nn.Module):
 
     @staticmethod
     def spatial_pushforward(dl, batch_size, sz, device, model):
-        """Reference :69-93: ``A_t`` (X,Y,Z,K,T) and the raw video ``Y`` (X,Y,Z,T) as float64 numpy for
-        every frame the loader yields.  ``Y_i`` (nearest-neighbour registration) is not produced by this
-        build yet and is returned as zeros."""
+        """Reference :69-93: ``A_t`` (X,Y,Z,K,T), the registered video ``Y_i`` and the raw video ``Y`` (X,Y,Z,T)
+        as float64 numpy for every frame the loader yields (K1 + K7)."""
         X, Y_, Z = _sz_list(sz)
-        K = model.C.shape[0]
-        A_list, Y_list = [], []
+        A_list, Y_list, Yi_list = [], [], []
         for data in dl:
             times = data[1].tolist()
-            A_t, _ = ops.warp_gather(model.fp.A.contiguous(), model.fp.beta.detach(), times, want_grid=False)
+            beta = model.fp.beta.detach()
+            A_t, _ = ops.warp_gather(model.fp.A.contiguous(), beta, times, want_grid=False)
             A_list.append(A_t.permute(2, 3, 4, 1, 0).double().cpu().numpy())
             Y_list.append(data[0].permute(1, 2, 3, 0).double().cpu().numpy())
-        A_t = np.concatenate(A_list, 4)
-        Yv = np.concatenate(Y_list, 3)
-        return A_t, np.zeros_like(Yv), Yv
+            fr = data[0].to(device, torch.float32).reshape(len(times), -1).contiguous()
+            Yi = ops.image_iwarp(fr, None, (X, Y_, Z), beta, times)
+            Yi_list.append(Yi.view(len(times), X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy())
+        return np.concatenate(A_list, 4), np.concatenate(Yi_list, 3), np.concatenate(Y_list, 3)
 
 
 class DeformableNMF:
@@ -202,16 +202,19 @@ class DeformableNMF:
 
     @staticmethod
     def update_spatial(A, C, Y_i, D=None, gamma=None):
-        """One multiplicative update of un-warped footprints (reference :151-160).  The reference's driver
-        never calls it (its call site is commented out); evaluated here with torch float64 on the GPU."""
+        """One multiplicative update of un-warped footprints (reference :151-160): numpy in, float64 numpy out.
+        ``A`` (..., K), ``C`` (K,T), ``Y_i`` (..., T), ``D`` None or like ``A``; the leading axes are the voxels
+        (the reference's einsum strings accept two of them, any number works here).  K5 + K6, fp32 MFMA."""
+        A, C, Y_i = np.asarray(A), np.asarray(C), np.asarray(Y_i)
+        K, T = C.shape
         dev = torch.device(device)
-        A_, C_, Y_ = (torch.from_numpy(np.asarray(v, dtype=np.float64)).to(dev) for v in (A, C, Y_i))
-        C_s = C_ @ C_.T
-        A1 = torch.einsum('mnt,kt->mnk', Y_, C_)
-        A2 = torch.einsum('mnk,kp->mnp', A_, C_s)
-        if D is not None:
-            A2 = A2 + gamma * torch.from_numpy(np.asarray(D, dtype=np.float64)).to(dev)
-        return (A_ * A1 / (A2 + 1e-32)).cpu().numpy()
+        A_dev = torch.from_numpy(np.ascontiguousarray(A.reshape(-1, K))).to(dev, torch.float32)
+        Y_dev = torch.from_numpy(np.ascontiguousarray(Y_i.reshape(-1, T).T)).to(dev, torch.float32)
+        C_dev = torch.from_numpy(np.ascontiguousarray(C)).to(dev, torch.float32)
+        D_dev = None if D is None else torch.from_numpy(np.ascontiguousarray(np.asarray(D).reshape(-1, K))).to(dev, torch.float32)
+        A1, Cs = ops.spatial_accum(Y_dev, C_dev)
+        ops.mu_spatial(A_dev, A1, Cs, D_dev, gamma)
+        return A_dev.double().cpu().numpy().reshape(A.shape)
 
     # ---- fit steps -------------------------------------------------------------------------------------
     def _gather_frames(self, loader):
@@ -228,7 +231,9 @@ class DeformableNMF:
         """Reference :163-179: ``iter_c`` multiplicative updates of ``self.C`` under the current warp.
 
         Returns ``(A_t, Y_i, Y)`` like the reference when the dense float64 ``A_t`` fits
-        ``DENSE_RETURN_LIMIT`` (or ``return_dense=True``); otherwise ``(None, None, None)``."""
+        ``DENSE_RETURN_LIMIT`` (or ``return_dense=True``); otherwise ``(None, None, None)``.
+        ``Y_i`` comes from the exhaustive nearest-neighbour search K7 (volumes up to 2^20 voxels, zeros beyond).
+        ``gamma_a`` is unused, as in the reference (its footprint update is commented out, :174)."""
         fp = self.fp
         K, P = fp.K, fp.P
         with torch.no_grad():
@@ -252,7 +257,12 @@ class DeformableNMF:
                 a, _ = ops.warp_gather(fp.A.contiguous(), fp.beta.detach(), order[s:s + step], want_grid=False)
                 A_t[..., s:s + step] = a.permute(2, 3, 4, 1, 0).double().cpu().numpy()
             Yv = frames.view(T_loc, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
-            return A_t, np.zeros_like(Yv), Yv
+            Yi = np.zeros_like(Yv)
+            if P <= (1 << 20):
+                for s in range(0, T_loc, 256):
+                    yi = ops.image_iwarp(frames, order[s:s + 256], fp.sz_list, fp.beta.detach(), order[s:s + 256])
+                    Yi[..., s:s + 256] = yi.view(-1, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
+            return A_t, Yi, Yv
 
     def _recon_cache(self, frame_ids=None):
         """Reconstruction images S_t = A.C_t of all T frames (C is constant inside update_motion)."""

@@ -29,6 +29,9 @@ SIGNATURES = {
                                 _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
+    "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
+    "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),
+    "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp]),
     "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _i, _d, _d, _d, _d, _i, _vp]),
     "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
 }

@@ -210,3 +210,54 @@ def adam_epoch(beta, grad, exp_avg, exp_avg_sq, step0, frame_step, nsteps, lr, b
                                            beta.shape[2], int(step0), fs.data_ptr(), int(nsteps), float(lr),
                                            float(betas[0]), float(betas[1]), float(eps), int(phase), _stream()),
                "dnmf_adam_epoch")
+
+
+def spatial_accum(Y, C, frame_ids=None, times=None, A1=None, Cs=None, accumulate=False):
+    """K5.  Y (>=T, ldy) frames, C (K, ldc) traces -> A1 (P,K) = Y^T C^T over the frames, Cs (K,K) = C C^T."""
+    if Y.dtype != torch.float32 or Y.stride(-1) != 1 or not Y.is_cuda:
+        raise ValueError("spatial_accum: Y must be float32 CUDA with unit inner stride")
+    if C.dtype != torch.float32 or C.stride(-1) != 1 or not C.is_cuda:
+        raise ValueError("spatial_accum: C must be float32 CUDA with unit inner stride")
+    dev = Y.device
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    tt = _i32(times, dev) if times is not None else None
+    T = fid.numel() if fid is not None else (tt.numel() if tt is not None else Y.shape[0])
+    P, K = Y.shape[1], C.shape[0]
+    if A1 is None:
+        A1 = torch.empty((P, K), dtype=torch.float32, device=dev)
+        Cs = torch.empty((K, K), dtype=torch.float32, device=dev)
+        accumulate = False
+    _lib.check(_lib.load().dnmf_spatial_accum(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), _ptr(tt),
+                                              T, P, K, A1.data_ptr(), Cs.data_ptr(), int(bool(accumulate)), _stream()),
+               "dnmf_spatial_accum")
+    return A1, Cs
+
+
+def mu_spatial(A, A1, Cs, D=None, gamma=0.0):
+    """K6.  A (P,K) fp32 updated in place: A * A1 / (A Cs + gamma D + 1e-32)."""
+    for t, n in ((A, "A"), (A1, "A1"), (Cs, "Cs")):
+        _f32(t, n)
+    if D is not None:
+        _f32(D, "D")
+    P, K = A.shape
+    _lib.check(_lib.load().dnmf_mu_spatial(A.data_ptr(), A1.data_ptr(), Cs.data_ptr(), _ptr(D), float(gamma or 0.0), P, K,
+                                           _stream()), "dnmf_mu_spatial")
+    return A
+
+
+def image_iwarp(frames, frame_ids, sz, beta, times):
+    """K7.  Registered frames (B,P): nearest-neighbour inverse warp under beta[:, :, times]."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    _f32(beta, "beta")
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("image_iwarp: frames must be float32 CUDA with unit inner stride")
+    dev = frames.device
+    tt = _i32(times, dev)
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = tt.numel()
+    out = torch.empty((B, P), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().dnmf_image_iwarp(frames.data_ptr(), frames.stride(0), _ptr(fid), X, Y, Z, beta.data_ptr(),
+                                            beta.shape[2], tt.data_ptr(), B, out.data_ptr(), out.stride(0), _stream()),
+               "dnmf_image_iwarp")
+    return out

@@ -124,6 +124,25 @@ int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, dou
                           int T, double gamma, const double *c_left, const double *c_right,
                           dnmf_stream_t stream);
 
+/* ---- K5 / K6: multiplicative update of the footprints -----------------------------------------------
+ * DeformableNMF.update_spatial (Demix/dNMF.py:151-160).
+ * dnmf_spatial_accum: A1[p,k] = sum_t Y[t,p] C[k,t] (fp32 MFMA, dNMF.py:154) and Cs = C C^T (dNMF.py:153) over
+ *   the T frames given: frame t at Y + frame_ids[t]*ldy (NULL -> t), trace column times[t] (NULL -> t);
+ *   accumulate != 0 adds to A1 / Cs instead of overwriting (frame chunks).  With the T axis sharded the caller
+ *   sums A1 (P,K) and Cs (K,K) over ranks (RCCL all-reduce) before dnmf_mu_spatial.
+ * dnmf_mu_spatial: A <- A * A1 / (A Cs + gamma D + 1e-32) in place (dNMF.py:155-159); D (P,K) or NULL. */
+int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const int *times,
+                       int T, long P, int K, float *A1, float *Cs, int accumulate, dnmf_stream_t stream);
+int dnmf_mu_spatial(float *A, const float *A1, const float *Cs, const float *D, double gamma, long P, int K,
+                    dnmf_stream_t stream);
+
+/* ---- K7: registered video ---------------------------------------------------------------------------
+ * ExponentialFP.image_iwarp over the frames of spatial_pushforward (Demix/dNMF.py:81-83, 89-91, 95-103): every
+ * lattice point takes the value of the voxel whose warped position ((n+1)/2 * sz, the reference's scaling
+ * there) is nearest.  Exhaustive search, P <= 2^20.  out (B,P) row stride ldo. */
+int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta,
+                     int T, const int *times, int B, float *out, long ldo, dnmf_stream_t stream);
+
 /* ---- Adam on beta for one epoch of mini-batches ------------------------------------------------------
  * update_motion steps the caller's torch.optim.Adam once per mini-batch on the whole (10,3,T) tensor
  * (Demix/dNMF.py:186-191; optimiser built at demo.py:42): columns outside the mini-batch get a zero gradient
