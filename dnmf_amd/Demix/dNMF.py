@@ -109,6 +109,8 @@ class ExponentialFP(nn.Module):
         self.A = A
         self._packed = None
         self._packed_version = None
+        self._sparse = None
+        self._sparse_version = None
 
     @staticmethod
     def quadratic_basis(P):
@@ -123,6 +125,30 @@ class ExponentialFP(nn.Module):
             self._packed = ops.pack_footprints(self.A.contiguous())
             self._packed_version = key
         return self._packed
+
+    def packed_sparse(self):
+        """Layout for the zero-skipping Gram kernel K3s: neurons ordered along a Z-order curve of their footprint
+        centroids, ``Aps`` (P,Ks) in that order, one block-occupancy byte per footprint row, and the mean
+        fraction of 16-neuron blocks that are non-zero per row (``occupancy``).  None if K > 128."""
+        if self.K > 128:
+            return None
+        key = (self.A.data_ptr(), self.A._version)
+        if self._sparse is None or self._sparse_version != key:
+            A2 = self.A.reshape(self.P, self.K)
+            mass = A2.sum(0).clamp_min(1e-30)
+            cen = (self.flow_id.reshape(self.P, 3).T @ A2) / mass            # (3,K) centroids
+            q = (cen[:2] / torch.tensor(self.sz_list[:2], device=cen.device)[:, None]).clamp(0, 1 - 1e-6)
+            q = (q * 1024).long().cpu().numpy()
+            code = np.zeros(self.K, dtype=np.int64)
+            for bit in range(10):                                           # interleave the bits of x and y
+                code |= ((q[0] >> bit) & 1) << (2 * bit + 1) | ((q[1] >> bit) & 1) << (2 * bit)
+            order = torch.from_numpy(np.argsort(code, kind="stable").astype(np.int32)).to(device)
+            Aps, mask = ops.pack_footprints_sparse(self.A.contiguous(), order)
+            nb = Aps.shape[1] // 16
+            bits = (mask[:, None] >> torch.arange(nb, device=mask.device, dtype=torch.uint8)[None, :]) & 1
+            self._sparse = {"Aps": Aps, "order": order, "row_mask": mask, "occupancy": float(bits.float().mean())}
+            self._sparse_version = key
+        return self._sparse
 
     def forward(self, times, C):
         """Returns ``(A_tC (B,X,Y,Z), A_t (B,K,X,Y,Z), grid (X,Y,Z,3,B), reg (B))`` for the frames ``times``."""
@@ -182,6 +208,10 @@ class DeformableNMF:
         # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
         # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
         self.fused_motion = True
+        # Gram kernel: 'dense' = K3 (every product evaluated), 'sparse' = K3s (products with an exact zero
+        # skipped; same sums), 'auto' = K3s when on average fewer than half of the 16-neuron blocks of a
+        # footprint row are non-zero
+        self.gram_kernel = 'auto'
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
     @staticmethod
@@ -239,8 +269,7 @@ class DeformableNMF:
         with torch.no_grad():
             frames, order = self._gather_frames(testloader)
             T_loc = frames.shape[0]
-            G, r, self._ws_k3 = ops.warp_gram_rhs(fp.packed_footprints(), K, fp.sz_list, fp.beta.detach(), order,
-                                                  frames, workspace=self._ws_k3)
+            G, r = self._gram_rhs(frames, order)
             Csel = self.C.to(device, torch.float32)[:, order.long()].contiguous()
             Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c)
             C = self.C.to(device, torch.float32).clone()
@@ -263,6 +292,18 @@ class DeformableNMF:
                     yi = ops.image_iwarp(frames, order[s:s + 256], fp.sz_list, fp.beta.detach(), order[s:s + 256])
                     Yi[..., s:s + 256] = yi.view(-1, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
             return A_t, Yi, Yv
+
+    def _gram_rhs(self, frames, order):
+        """Per-frame Gram matrices and right-hand sides under the current warp (K3 or K3s)."""
+        fp = self.fp
+        sp = fp.packed_sparse() if self.gram_kernel in ('auto', 'sparse') else None
+        if sp is not None and (self.gram_kernel == 'sparse' or sp["occupancy"] < 0.5):
+            G, r, self._ws_k3 = ops.warp_gram_rhs_sparse(sp["Aps"], fp.K, sp["order"], sp["row_mask"], fp.sz_list,
+                                                         fp.beta.detach(), order, frames, workspace=self._ws_k3)
+        else:
+            G, r, self._ws_k3 = ops.warp_gram_rhs(fp.packed_footprints(), fp.K, fp.sz_list, fp.beta.detach(), order,
+                                                  frames, workspace=self._ws_k3)
+        return G, r
 
     def _recon_cache(self, frame_ids=None):
         """Reconstruction images S_t = A.C_t of all T frames (C is constant inside update_motion)."""

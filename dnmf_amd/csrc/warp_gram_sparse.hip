@@ -1,0 +1,333 @@
+// K3s -- the Gram kernel with exact-zero block skipping.
+//
+// Same contraction as warp_gram_rhs.hip (G_t = A_t^T A_t, r_t = A_t^T y_t; reference Demix/dNMF.py:141-142), for
+// footprints that are exactly zero over most of the volume: the reference's Gaussians underflow to 0 in fp32
+// beyond ~30 px, and a multiplicative update keeps every zero a zero.  Products with an exact zero add nothing,
+// so leaving them out changes no sum.
+//
+// Neurons are ordered along a space-filling curve (host) and cut into blocks of 16 channels; every footprint
+// row carries a bit mask of the blocks in which it has a non-zero.  For each pass of 64 voxels a wave ORs the
+// masks of all source rows it is about to gather (wave-uniform set S), gathers and blends ONLY the blocks in S
+// for the 16 k-steps of the pass, and issues the MFMAs of tile (bi,bj) only if both blocks are in S; a pass
+// with S empty costs the coordinate pass and nothing else.  Accumulators stay statically indexed: the skips are
+// scalar branches around fully unrolled code.  The right-hand side is accumulated on the vector ALU.
+#include "common.hpp"
+
+namespace dnmf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KS_SS = 64;          // voxels per pass
+constexpr int KS_NKS = KS_SS / 4;  // k-steps per pass
+
+__host__ __device__ constexpr int sp_tile_index(int NB, int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
+
+// Aps[p][c] = c < K ? A[p][order[c]] : 0 ;  row_mask[p] bit b = any(Aps[p][16b .. 16b+15] != 0)
+__global__ __launch_bounds__(256) void pack_sparse_kernel(const float *__restrict__ A, long P, int K,
+                                                          const int *__restrict__ order, float *__restrict__ Aps,
+                                                          int Ks, unsigned char *__restrict__ row_mask) {
+    const int sub = threadIdx.x & 15;                                  // 16 threads per row
+    const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (p >= P) return;  // rows are handed out in groups of 16 lanes: a group leaves together
+    unsigned m = 0;
+    for (int b = 0; b < Ks / 16; ++b) {
+        const int c = 16 * b + sub;
+        const float v = c < K ? A[p * K + order[c]] : 0.0f;
+        Aps[p * Ks + c] = v;
+        unsigned nz = v != 0.0f ? 1u : 0u;
+        nz |= __shfl_xor(nz, 1, 16);
+        nz |= __shfl_xor(nz, 2, 16);
+        nz |= __shfl_xor(nz, 4, 16);
+        nz |= __shfl_xor(nz, 8, 16);
+        m |= nz << b;
+    }
+    if (sub == 0) row_mask[p] = (unsigned char)m;
+}
+
+struct SparseParams {
+    const float *Aps;
+    const unsigned char *row_mask;
+    int Ks, K;
+    Volume vol;
+    const float *beta;
+    int T;
+    const int *times;
+    int B;
+    const float *frames;
+    long ldf;
+    const int *frame_ids;
+    float *slab;  // (B, nchunks, NT*256 + 128)
+    int nchunks;
+    long chunk_len;
+};
+
+template <int NB, int NTAP>
+__global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NQ = NTAP / 4;
+    constexpr int SLAB = NT * 256 + 128;
+    __shared__ u32x4 s_row[4][NQ][KS_SS];
+    __shared__ f32x4 s_w[4][NQ][KS_SS];
+    __shared__ float s_y[4][KS_SS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)p.nchunks * p.B) return;
+    const int chunk = (int)(item / p.B);
+    const int b = (int)(item - (long)chunk * p.B);
+    const int t = p.times ? p.times[b] : b;
+    const char *__restrict__ Ab = reinterpret_cast<const char *>(p.Aps);
+    const float *__restrict__ yb = p.frames + (long)(p.frame_ids ? p.frame_ids[b] : b) * p.ldf;
+    const Volume vol = p.vol;
+    const unsigned row_bytes = (unsigned)p.Ks * 4u;
+
+    float bt[30];
+    load_beta(p.beta, p.T, t, bt);
+    const int ci = lane & 15, vq = lane >> 4;
+    const unsigned lane_off = 4u * ci;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float racc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) racc[i] = 0.0f;
+
+    const long v_begin = (long)chunk * p.chunk_len;
+    const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
+    const int nss = (int)((v_end - v_begin + KS_SS - 1) / KS_SS);
+
+    for (int s = 0; s < nss; ++s) {
+        // ---- coordinate pass + block set of the pass ------------------------------------------------------
+        unsigned m = 0;
+        {
+            const long v = v_begin + (long)s * KS_SS + lane;
+            unsigned rows[NTAP];
+            float w[NTAP];
+            float yv = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
+            if (v < v_end) {
+                int x, y, z;
+                voxel_xyz(v, vol, x, y, z);
+                const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
+#pragma unroll
+                for (int c = 0; c < NTAP; ++c) {
+                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                    const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
+                    bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y);
+                    float wc = __fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0);
+                    unsigned vox = (unsigned)(cx * vol.Y + cy);
+                    if (NTAP == 8) {
+                        ok = ok && in_range(cz, vol.Z);
+                        wc = __fmul_rn(wc, dz ? sm.wz1 : sm.wz0);
+                        vox = vox * (unsigned)vol.Z + (unsigned)cz;
+                    }
+                    w[c] = ok ? wc : 0.0f;
+                    rows[c] = ok ? vox * row_bytes : 0u;
+                    if (ok) m |= p.row_mask[vox];
+                }
+                yv = yb[v];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                s_row[wave][q][lane] = u32x4{rows[4 * q], rows[4 * q + 1], rows[4 * q + 2], rows[4 * q + 3]};
+                s_w[wave][q][lane] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            }
+            s_y[wave][lane] = yv;
+        }
+        unsigned S = 0;  // wave-uniform: blocks with a non-zero in some source row of this pass
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) S |= (__ballot((m >> bb) & 1u) != 0ull ? 1u : 0u) << bb;
+        S = __builtin_amdgcn_readfirstlane(S);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        if (S != 0) {
+            // ---- gather + blend the active blocks for all 16 k-steps ---------------------------------------
+            float frag[NB][KS_NKS];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                if ((S >> bb) & 1u) {
+                    const unsigned boff = 64u * bb + lane_off;
+#pragma unroll
+                    for (int ks = 0; ks < KS_NKS; ++ks) {
+                        const int vi = ks * 4 + vq;
+                        float v = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const u32x4 rr = s_row[wave][q][vi];
+                            const f32x4 ww = s_w[wave][q][vi];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v = fmaf(*reinterpret_cast<const float *>(Ab + (size_t)(rr[e] + boff)), ww[e], v);
+                        }
+                        frag[bb][ks] = v;
+                        racc[bb] = fmaf(v, s_y[wave][vi], racc[bb]);
+                    }
+                }
+            }
+            // ---- MFMAs of the tiles whose two blocks are both active ---------------------------------------
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                if ((S >> bi) & 1u) {
+#pragma unroll
+                    for (int bj = bi; bj < NB; ++bj) {
+                        if ((S >> bj) & 1u) {
+                            const int idx = sp_tile_index(NB, bi, bj);
+#pragma unroll
+                            for (int ks = 0; ks < KS_NKS; ++ks)
+                                acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[bi][ks], frag[bj][ks], acc[idx], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // the next coordinate pass overwrites the records: keep it behind this pass's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    float *out = p.slab + ((long)b * p.nchunks + chunk) * SLAB;
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(out) + lane;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out4[(long)i * 64] = acc[i];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        float v = racc[bb];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (vq == 0) out[NT * 256 + 16 * bb + ci] = v;
+    }
+}
+
+// ordered chunk sum + scatter through the neuron order (sorted channel c -> neuron order[c])
+template <int NB>
+__global__ __launch_bounds__(256) void gram_sparse_finish_kernel(const float *__restrict__ slab, int nchunks, int K,
+                                                                 const int *__restrict__ order, float *__restrict__ G,
+                                                                 float *__restrict__ r) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int SLAB = NT * 256 + 128;
+    const int b = blockIdx.x;
+    const int e = threadIdx.x;
+    const int lane = e >> 2, reg = e & 3;
+    const int i = 4 * (lane >> 4) + reg, j = lane & 15;
+    float *Gb = G + (long)b * K * K;
+    const float *base = slab + (long)b * nchunks * SLAB;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+            const float *src = base + sp_tile_index(NB, bi, bj) * 256 + e;
+            float s = 0.0f;
+            for (int c = 0; c < nchunks; ++c) s += src[(long)c * SLAB];
+            const int ck = 16 * bi + i, cl = 16 * bj + j;
+            if (ck < K && cl < K) {
+                const int k = order[ck], l = order[cl];
+                Gb[(long)k * K + l] = s;
+                Gb[(long)l * K + k] = s;
+            }
+        }
+    }
+    if (e < 16 * NB && e < K) {
+        float s = 0.0f;
+        for (int c = 0; c < nchunks; ++c) s += base[(long)c * SLAB + NT * 256 + e];
+        r[(long)b * K + order[e]] = s;
+    }
+}
+
+static void sp_choose_chunks(long P, int B, int &nchunks, long &chunk_len) {
+    const long nss = (P + KS_SS - 1) / KS_SS;
+    long want = (8192 + B - 1) / B;  // passes differ a lot in cost: more, smaller work items than the dense kernel
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    if (want > nss) want = nss;
+    const long ss_per_chunk = (nss + want - 1) / want;
+    chunk_len = ss_per_chunk * KS_SS;
+    nchunks = (int)((P + chunk_len - 1) / chunk_len);
+}
+
+template <int NB>
+static int launch_sparse(SparseParams p, const int *order, float *G, float *r, hipStream_t st) {
+    const long nitems = (long)p.nchunks * p.B;
+    const unsigned nwg = (unsigned)((nitems + 3) / 4);
+    if (p.vol.Z > 1)
+        hipLaunchKernelGGL((warp_gram_sparse_kernel<NB, 8>), dim3(nwg), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((warp_gram_sparse_kernel<NB, 4>), dim3(nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gram_sparse_finish_kernel<NB>), dim3((unsigned)p.B), dim3(256), 0, st, p.slab, p.nchunks, p.K,
+                       order, G, r);
+    return check_launch("dnmf_warp_gram_rhs_sparse");
+}
+
+}  // namespace dnmf
+
+extern "C" {
+
+int dnmf_sparse_k(int K) { return K < 1 ? 0 : 16 * ((K + 15) / 16); }
+
+int dnmf_pack_footprints_sparse(const float *A, long P, int K, const int *order, float *Aps, int Ks,
+                                unsigned char *row_mask, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(A && order && Aps && row_mask, DNMF_E_NULL, "dnmf_pack_footprints_sparse: NULL buffer");
+    DNMF_REQUIRE(P > 0 && K > 0 && Ks == dnmf_sparse_k(K), DNMF_E_SHAPE, "dnmf_pack_footprints_sparse: P=%ld K=%d Ks=%d", P,
+                 K, Ks);
+    DNMF_REQUIRE(Ks <= 128, DNMF_E_UNSUPPORTED, "dnmf_pack_footprints_sparse: K=%d > 128 (8 blocks per mask byte)", K);
+    const long nthreads = P * 16;
+    hipLaunchKernelGGL(pack_sparse_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A,
+                       P, K, order, Aps, Ks, row_mask);
+    return check_launch("dnmf_pack_footprints_sparse");
+}
+
+size_t dnmf_warp_gram_rhs_sparse_workspace(long P, int K, int B) {
+    if (P <= 0 || K <= 0 || B <= 0) return 0;
+    const int NB = dnmf_sparse_k(K) / 16;
+    int nchunks;
+    long chunk_len;
+    dnmf::sp_choose_chunks(P, B, nchunks, chunk_len);
+    return (size_t)B * nchunks * ((size_t)(NB * (NB + 1) / 2) * 256 + 128) * sizeof(float);
+}
+
+int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask, int X,
+                              int Y, int Z, const float *beta, int T, const int *times, int B, const float *frames,
+                              long ldf, const int *frame_ids, float *G, float *r, void *workspace,
+                              size_t workspace_bytes, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(Aps && order && row_mask && beta && frames && G && r && workspace, DNMF_E_NULL,
+                 "dnmf_warp_gram_rhs_sparse: NULL buffer");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && Ks == dnmf_sparse_k(K), DNMF_E_SHAPE,
+                 "dnmf_warp_gram_rhs_sparse: X=%d Y=%d Z=%d K=%d Ks=%d T=%d B=%d", X, Y, Z, K, Ks, T, B);
+    DNMF_REQUIRE(Ks <= 128, DNMF_E_UNSUPPORTED, "dnmf_warp_gram_rhs_sparse: K=%d > 128", K);
+    SparseParams p;
+    p.vol = make_volume(X, Y, Z);
+    DNMF_REQUIRE(ldf >= p.vol.P, DNMF_E_SHAPE, "dnmf_warp_gram_rhs_sparse: ldf=%ld < P=%ld", ldf, p.vol.P);
+    DNMF_REQUIRE(p.vol.P * Ks < (1L << 30), DNMF_E_UNSUPPORTED, "dnmf_warp_gram_rhs_sparse: P*Ks=%ld too large",
+                 p.vol.P * Ks);
+    DNMF_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, DNMF_E_SHAPE,
+                 "dnmf_warp_gram_rhs_sparse: workspace must be 16-byte aligned");
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_gram_rhs_sparse_workspace(p.vol.P, K, B), DNMF_E_WORKSPACE,
+                 "dnmf_warp_gram_rhs_sparse: workspace %zu < %zu bytes", workspace_bytes,
+                 dnmf_warp_gram_rhs_sparse_workspace(p.vol.P, K, B));
+    p.Aps = Aps, p.row_mask = row_mask, p.Ks = Ks, p.K = K;
+    p.beta = beta, p.T = T, p.times = times, p.B = B;
+    p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
+    p.slab = static_cast<float *>(workspace);
+    sp_choose_chunks(p.vol.P, B, p.nchunks, p.chunk_len);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Ks / 16) {
+        case 1: return launch_sparse<1>(p, order, G, r, st);
+        case 2: return launch_sparse<2>(p, order, G, r, st);
+        case 3: return launch_sparse<3>(p, order, G, r, st);
+        case 4: return launch_sparse<4>(p, order, G, r, st);
+        case 5: return launch_sparse<5>(p, order, G, r, st);
+        case 6: return launch_sparse<6>(p, order, G, r, st);
+        case 7: return launch_sparse<7>(p, order, G, r, st);
+        default: return launch_sparse<8>(p, order, G, r, st);
+    }
+}
+
+}  // extern "C"

@@ -261,3 +261,44 @@ def image_iwarp(frames, frame_ids, sz, beta, times):
                                             beta.shape[2], tt.data_ptr(), B, out.data_ptr(), out.stride(0), _stream()),
                "dnmf_image_iwarp")
     return out
+
+
+def pack_footprints_sparse(A, order):
+    """A (..., K) and a neuron order -> (Aps (P,Ks), row_mask (P) uint8) for the zero-skipping Gram kernel."""
+    K = A.shape[-1]
+    A2 = _f32(A.reshape(-1, K), "A")
+    lib = _lib.load()
+    Ks = lib.dnmf_sparse_k(K)
+    od = _i32(order, A.device)
+    Aps = torch.empty((A2.shape[0], Ks), dtype=torch.float32, device=A.device)
+    mask = torch.empty((A2.shape[0],), dtype=torch.uint8, device=A.device)
+    _lib.check(lib.dnmf_pack_footprints_sparse(A2.data_ptr(), A2.shape[0], K, od.data_ptr(), Aps.data_ptr(), Ks,
+                                               mask.data_ptr(), _stream()), "dnmf_pack_footprints_sparse")
+    return Aps, mask
+
+
+def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame_ids=None, workspace=None):
+    """K3s.  Returns G (B,K,K), r (B,K) in the original neuron order."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    dev = Aps.device
+    _f32(Aps, "Aps"), _f32(beta, "beta")
+    lib = _lib.load()
+    od = _i32(order, dev)
+    tt = _i32(times, dev) if times is not None else None
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = tt.numel() if tt is not None else (fid.numel() if fid is not None else frames.shape[0])
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("warp_gram_rhs_sparse: frames must be float32 CUDA with unit inner stride")
+    need = lib.dnmf_warp_gram_rhs_sparse_workspace(P, K, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
+    r = torch.empty((B, K), dtype=torch.float32, device=dev)
+    with _timed("warp_gram_rhs_sparse"):
+        rc = lib.dnmf_warp_gram_rhs_sparse(
+            Aps.data_ptr(), Aps.shape[-1], K, od.data_ptr(), row_mask.data_ptr(), X, Y, Z, beta.data_ptr(),
+            beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(),
+            workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream())
+    _lib.check(rc, "dnmf_warp_gram_rhs_sparse")
+    return G, r, workspace

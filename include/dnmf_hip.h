@@ -106,6 +106,23 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
                        const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
                        dnmf_stream_t stream);
 
+/* ---- K3s: the same contraction with exact-zero block skipping ---------------------------------------------
+ * For footprints that are exactly zero over most of the volume (the reference's Gaussians underflow to 0 in
+ * fp32 beyond ~30 px; multiplicative updates keep zeros).  Neurons are taken in the order `order` (K ints, sorted
+ * channel -> neuron; the caller sorts them along a space-filling curve) and cut into blocks of 16; a product in
+ * which either factor is an exact zero is not evaluated, which changes no sum.
+ * dnmf_pack_footprints_sparse: Aps (P,Ks) <- A[:, order], Ks = dnmf_sparse_k(K) = 16*ceil(K/16), zero padded;
+ *   row_mask[p] bit b = row p has a non-zero among channels 16b..16b+15.  K <= 128.
+ * dnmf_warp_gram_rhs_sparse: arguments as dnmf_warp_gram_rhs; G, r come out in the ORIGINAL neuron order. */
+int dnmf_sparse_k(int K);
+int dnmf_pack_footprints_sparse(const float *A, long P, int K, const int *order, float *Aps, int Ks,
+                                unsigned char *row_mask, dnmf_stream_t stream);
+size_t dnmf_warp_gram_rhs_sparse_workspace(long P, int K, int B);
+int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask,
+                              int X, int Y, int Z, const float *beta, int T, const int *times, int B,
+                              const float *frames, long ldf, const int *frame_ids, float *G, float *r,
+                              void *workspace, size_t workspace_bytes, dnmf_stream_t stream);
+
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
  * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.

@@ -422,3 +422,60 @@ def test_demo_loop_recovers_traces(M, capsys):
     assert "Epoch 1" in out.stdout and "Recon: " in out.stdout and "Reg: " in out.stdout
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("trace correlation")][0]
     assert 0.15 < float(line.split("median")[1]) < 0.35, line
+
+
+@pytest.mark.parametrize("sz,K,T,sigma", [([96, 80, 1], 40, 5, 1.0), ([64, 48, 2], 100, 3, 0.7), ([40, 36, 3], 20, 4, 3.0),
+                                          ([33, 47, 1], 7, 6, 0.8)])
+def test_sparse_gram_equals_dense(M, O, sz, K, T, sigma):
+    """K3s (products with an exact zero skipped) against K3 and against the float64 oracle: footprints narrow
+    enough to underflow to exact zeros (sigma <= 1), and a dense case where nothing can be skipped."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(K)
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, sigma))
+    beta = O.identity_beta(T)
+    beta += (rng.randn(10, 3, T) * np.array([1.5, 1e-2, 1e-2, 1e-2, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4])[:, None, None]
+             ).astype(np.float32)
+    if sz[2] == 1:
+        beta[:, 2] = O.identity_beta(T)[:, 2]
+    video = rng.rand(*sz, T).astype(np.float32)
+    fp = make_fp(M, sz, K, T, pos, beta=beta, A=A)
+    frames = dev(np.moveaxis(video, -1, 0)).reshape(T, -1)
+    sp = fp.packed_sparse()
+    assert sorted(sp["order"].tolist()) == list(range(K))
+    if sigma <= 1.0:
+        assert sp["occupancy"] < 0.6 and float((fp.A == 0).float().mean()) > 0.5
+    Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), list(range(T)), frames)
+    Gs, rs, _ = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), list(range(T)),
+                                         frames)
+    # same products, same fp32 arithmetic; only the grouping of the partial sums differs
+    gs, rsc = float(Gd.abs().max()), float(rd.abs().max())
+    assert float((Gs - Gd).abs().max()) < 2e-6 * gs and float((rs - rd).abs().max()) < 2e-6 * rsc
+    assert torch.equal(Gs, Gs.transpose(1, 2))
+    lat = O.voxel_lattice(sz)
+    _, A_t, _, _ = O.forward(A, O.quadratic_basis(lat), beta, sz, list(range(T)), np.zeros((K, T), np.float32),
+                             O.trilinear_sample_torch)
+    Gref, rref = O.gram_rhs(np.transpose(A_t.astype(np.float64), [2, 3, 4, 1, 0]), video.astype(np.float64))
+    np.testing.assert_allclose(Gs.cpu().numpy(), np.moveaxis(Gref, 2, 0), rtol=2e-5, atol=2e-5 * np.abs(Gref).max())
+    np.testing.assert_allclose(rs.cpu().numpy(), rref.T, rtol=2e-5, atol=2e-5 * np.abs(rref).max())
+
+
+def test_sparse_gram_full_size(M):
+    """512x512, K=100, the bench geometry: K3s == K3 on every frame."""
+    from dnmf_amd import ops
+    torch.manual_seed(0)
+    sz, K, T = [512, 512, 1], 100, 8
+    pos = torch.rand(K, 3) * torch.tensor([512.0, 512.0, 0.0])
+    fp = M.ExponentialFP(torch.tensor(sz), K, T, positions=pos)
+    with torch.no_grad():
+        scale = torch.tensor([2.0, 2e-3, 2e-3, 0, 2e-6, 2e-6, 0, 2e-6, 0, 0], device="cuda")
+        fp.beta += scale[:, None, None] * torch.randn_like(fp.beta)
+        fp.beta[:, 2] = 0
+        fp.beta[3, 2] = 1
+    frames = torch.rand(T, 512 * 512, device="cuda")
+    sp = fp.packed_sparse()
+    Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames)
+    Gs, rs, _ = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None, frames)
+    assert float((Gs - Gd).abs().max()) < 2e-6 * float(Gd.abs().max())
+    assert float((rs - rd).abs().max()) < 2e-6 * float(rd.abs().max())
+    assert 0.05 < sp["occupancy"] < 0.5

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--neurons", type=int, default=100)
     ap.add_argument("--z", type=int, default=1)
     ap.add_argument("--jitter", type=float, default=1e-3, help="random perturbation of beta (0 = identity warp)")
+    ap.add_argument("--sparse", action="store_true", help="run the zero-skipping kernel K3s instead of K3")
     a = ap.parse_args()
     from dnmf_amd import ops
     from dnmf_amd.Demix import dNMF as M
@@ -37,7 +38,12 @@ def main():
     for _ in range(a.reps):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        G, r, ws = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames, workspace=ws)
+        if a.sparse:
+            sp = fp.packed_sparse()
+            G, r, ws = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None,
+                                                frames, workspace=ws)
+        else:
+            G, r, ws = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames, workspace=ws)
         e.record()
         ev.append((s, e))
     torch.cuda.synchronize()
@@ -45,7 +51,9 @@ def main():
     P = fp.P
     ntap = 8 if a.z > 1 else 4
     flops = T * (P * K * (K + 1) + 2 * P * K + 2 * ntap * P * K)
-    print(f"K3 {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
+    if a.sparse:
+        print("occupancy", fp.packed_sparse()["occupancy"])
+    print(f"K3{'s' if a.sparse else ''} {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
 
 
 if __name__ == "__main__":
