@@ -13,7 +13,7 @@ T=4000, K=100, fp32.  N>1: the T axis is sharded, every rank holds 4000 frames o
 barrier.  The video is generated on the GPU before the timed region starts (inputs resident in HBM).
 
 Rank 0 prints ONE JSON line; it also carries
-  roofline      the dominant kernel (K3 warp_gram_kernel, fp32 MFMA) timed with HIP events on its stream
+  roofline      the dominant kernel (the Gram kernel K3s / K3, fp32 MFMA) timed with HIP events on its stream
   cpu_baseline  the CPU oracle (reference op sequence) timed on this host on a bounded sample, N=1 only
 """
 import argparse
@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iter-c", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gram", choices=["auto", "dense", "sparse"], default="auto",
+                    help="Gram kernel: K3 (dense), K3s (exact-zero blocks skipped) or by footprint occupancy")
     return ap.parse_args()
 
 
@@ -114,6 +116,7 @@ def main():
     torch.manual_seed(1 + rank)
     dn = M.DeformableNMF(torch.tensor(sz), K, T_loc, positions=positions0)
     dn.verbose = False
+    dn.gram_kernel = args.gram
     opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
     # every rank draws the SAME global mini-batch order and keeps its own frames: the optimiser-step sequence
     # is the single-process one for the 4000*N-frame video (dnmf_amd/sharding.py)
@@ -146,16 +149,51 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt[0])
 
+    # one launch of the dense Gram kernel outside the timed region, for the roofline of the kernel that
+    # evaluates every product (the timed sweeps may have used the zero-skipping kernel instead)
+    dense_ms = None
     if rank == 0:
-        k3 = [a.elapsed_time(b) * 1e-3 for a, b in timing.get("warp_gram_rhs", [])]
-        k2 = [a.elapsed_time(b) * 1e-3 for a, b in timing.get("warp_recon_grad", [])]
+        torch.cuda.synchronize()
+        ops.TIMING = {}
+        ops.warp_gram_rhs(dn.fp.packed_footprints(), K, sz, dn.fp.beta.detach(), None, frames)
+        torch.cuda.synchronize()
+        (a, b), = ops.TIMING["warp_gram_rhs"]
+        dense_ms, ops.TIMING = a.elapsed_time(b), None
+
+    if rank == 0:
+        def evs(name):
+            return [a.elapsed_time(b) * 1e-3 for a, b in timing.get(name, [])]
+        k3d, k3s, k2 = evs("warp_gram_rhs"), evs("warp_gram_rhs_sparse"), evs("warp_recon_grad")
+        sparse = len(k3s) > 0
+        k3 = k3s if sparse else k3d
         k3_avg = sum(k3) / max(1, len(k3))
-        # algorithmic flops of one K3 launch (symmetric Gram exploited, bilinear = 4 taps)
-        flops = T_loc * (P * K * (K + 1) + 2 * P * K + 8 * P * K)
-        traffic = None
+        # algorithmic flops of one Gram launch when every product is evaluated (symmetric Gram,
+        # rhs, 4 bilinear taps)
+        dense_flops = T_loc * (P * K * (K + 1) + 2 * P * K + 8 * P * K)
+        tjson = {}
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{size}x{size}x{T_loc}_K{K}")
+            tjson = json.load(open(tpath))
+        key = f"{size}x{size}x{T_loc}_K{K}"
+        if sparse:
+            # flops of the products that were not skipped, from the kernel's own counters: an MFMA is
+            # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (4 taps + rhs) FMAs
+            n_mfma, n_blend = (float(v) / len(k3s) for v in ops.SPARSE_COUNTERS.tolist())
+            flops = n_mfma * 2048 + n_blend * 64 * 2 * 5
+            roof = {"kernel": "warp_gram_sparse_kernel<7,4> (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",
+                    "bound": "mfma", "achieved": flops / k3_avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": tjson.get(key + "_sparse"),
+                    "launch_ms": 1e3 * k3_avg, "launches": len(k3s), "flops_per_launch": flops,
+                    "count": "flops of the products evaluated (16-neuron blocks that are non-zero in a half pass of 32 "
+                             "voxels), from in-kernel counters; products with an exact zero are skipped",
+                    "dense_equivalent_flops_per_launch": dense_flops,
+                    "dense_equivalent_tflops": dense_flops / k3_avg / 1e12}
+        else:
+            roof = {"kernel": "warp_gram_kernel<7,4> (K3, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
+                    "achieved": dense_flops / k3_avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": dense_flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": tjson.get(key),
+                    "launch_ms": 1e3 * k3_avg, "launches": len(k3), "flops_per_launch": dense_flops,
+                    "count": "P*K*(K+1) symmetric Gram + 2PK rhs + 8PK bilinear taps, per frame"}
         line = {
             "metric": "frames/sec demixed, 512x512xT K=100",
             "value": T_total * args.steps / elapsed,
@@ -166,15 +204,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Simulator {size}x{size}x{T_total} (Z=1), K={K}, fp32: update_motion(epochs=1, "
                                    f"batch {bs}, Adam lr 1e-5) + update_footprints(iter_c={args.iter_c}, gamma_c=0)",
-                       "frames_per_gpu": T_loc, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
-            "roofline": {"kernel": "warp_gram_kernel<7,4> (K3, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
-                         "achieved": flops / k3_avg / 1e12 if k3_avg else None, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s",
-                         "frac": flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS if k3_avg else None,
-                         "traffic": traffic, "launch_ms": 1e3 * k3_avg, "launches": len(k3),
-                         "flops_per_launch": flops,
-                         "count": "P*K*(K+1) symmetric Gram + 2PK rhs + 8PK bilinear taps, per frame"},
-            "breakdown_ms_per_step": {"K3_gram": 1e3 * sum(k3) / args.steps, "K2_motion_kernels": 1e3 * sum(k2) / args.steps},
+                       "frames_per_gpu": T_loc, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "gram_kernel": dn.gram_kernel + (" -> zero-skipping" if sparse else " -> dense")},
+            "roofline": roof,
+            "roofline_dense_kernel": {
+                "kernel": "warp_gram_kernel<7,4> (K3): every product evaluated, one launch outside the timed region",
+                "bound": "mfma", "achieved": dense_flops / (dense_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": dense_flops / (dense_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "traffic": tjson.get(key), "launch_ms": dense_ms, "flops_per_launch": dense_flops},
+            "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps, "K2_motion_kernels": 1e3 * sum(k2) / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy())

@@ -31,7 +31,7 @@ SIGNATURES = {
     "dnmf_pack_footprints_sparse": (_i, [_vp, _l, _i, _vp, _vp, _i, _vp, _vp]),
     "dnmf_warp_gram_rhs_sparse_workspace": (_sz, [_l, _i, _i]),
     "dnmf_warp_gram_rhs_sparse": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp,
-                                       _sz, _vp]),
+                                       _sz, _vp, _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
     "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),

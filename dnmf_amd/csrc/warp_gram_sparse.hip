@@ -8,8 +8,8 @@
 // Neurons are ordered along a space-filling curve (host) and cut into blocks of 16 channels; every footprint
 // row carries a bit mask of the blocks in which it has a non-zero.  For each pass of 64 voxels a wave ORs the
 // masks of all source rows it is about to gather (wave-uniform set S), gathers and blends ONLY the blocks in S
-// for the 16 k-steps of the pass, and issues the MFMAs of tile (bi,bj) only if both blocks are in S; a pass
-// with S empty costs the coordinate pass and nothing else.  Accumulators stay statically indexed: the skips are
+// for the 8 k-steps of each half pass (one set per half), and issues the MFMAs of tile (bi,bj) only if both
+// blocks are in S; a half pass with S empty costs its share of the coordinate pass and nothing else.  Accumulators stay statically indexed: the skips are
 // scalar branches around fully unrolled code.  The right-hand side is accumulated on the vector ALU.
 #include "common.hpp"
 
@@ -20,6 +20,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KS_SS = 64;          // voxels per pass
 constexpr int KS_NKS = KS_SS / 4;  // k-steps per pass
+constexpr int KS_HALF = KS_NKS / 2;  // k-steps per half pass (block sets are per half)
 
 __host__ __device__ constexpr int sp_tile_index(int NB, int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
 
@@ -60,10 +61,11 @@ struct SparseParams {
     float *slab;  // (B, nchunks, NT*256 + 128)
     int nchunks;
     long chunk_len;
+    unsigned long long *counters;  // optional: [0] += MFMAs issued, [1] += (active block, k-step) blends
 };
 
 template <int NB, int NTAP>
-__global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p) {
+__global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kernel(SparseParams p) {
     constexpr int NT = NB * (NB + 1) / 2;
     constexpr int NQ = NTAP / 4;
     constexpr int SLAB = NT * 256 + 128;
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p
     const long v_begin = (long)chunk * p.chunk_len;
     const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
     const int nss = (int)((v_end - v_begin + KS_SS - 1) / KS_SS);
+    unsigned n_tiles = 0, n_blocks = 0;  // (tile, half pass) and (block, half pass) pairs executed
 
     for (int s = 0; s < nss; ++s) {
         // ---- coordinate pass + block set of the pass ------------------------------------------------------
@@ -138,24 +141,34 @@ __global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p
             }
             s_y[wave][lane] = yv;
         }
-        unsigned S = 0;  // wave-uniform: blocks with a non-zero in some source row of this pass
+        // wave-uniform block sets of the two half passes (lanes 0-31 hold voxels 0-31 = k-steps 0-7)
+        unsigned S2[2] = {0u, 0u};
 #pragma unroll
-        for (int bb = 0; bb < NB; ++bb) S |= (__ballot((m >> bb) & 1u) != 0ull ? 1u : 0u) << bb;
-        S = __builtin_amdgcn_readfirstlane(S);
+        for (int bb = 0; bb < NB; ++bb) {
+            const unsigned long long bal = __ballot((m >> bb) & 1u);
+            S2[0] |= ((unsigned)(bal & 0xffffffffull) != 0u ? 1u : 0u) << bb;
+            S2[1] |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << bb;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        if (S != 0) {
-            // ---- gather + blend the active blocks for all 16 k-steps ---------------------------------------
-            float frag[NB][KS_NKS];
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const unsigned S = __builtin_amdgcn_readfirstlane(S2[h]);
+            if (S == 0) continue;
+            const int ks0 = h * KS_HALF;
+            const int na = __builtin_popcount(S);
+            n_blocks += na, n_tiles += na * (na + 1) / 2;
+            // ---- gather + blend the active blocks for the 8 k-steps of this half -----------------------------
+            float frag[NB][KS_HALF];
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
                 if ((S >> bb) & 1u) {
                     const unsigned boff = 64u * bb + lane_off;
 #pragma unroll
-                    for (int ks = 0; ks < KS_NKS; ++ks) {
-                        const int vi = ks * 4 + vq;
+                    for (int ks = 0; ks < KS_HALF; ++ks) {
+                        const int vi = (ks0 + ks) * 4 + vq;
                         float v = 0.0f;
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p
                     }
                 }
             }
-            // ---- MFMAs of the tiles whose two blocks are both active ---------------------------------------
+            // ---- MFMAs of the tiles whose two blocks are both active -----------------------------------------
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
                 if ((S >> bi) & 1u) {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p
                         if ((S >> bj) & 1u) {
                             const int idx = sp_tile_index(NB, bi, bj);
 #pragma unroll
-                            for (int ks = 0; ks < KS_NKS; ++ks)
+                            for (int ks = 0; ks < KS_HALF; ++ks)
                                 acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[bi][ks], frag[bj][ks], acc[idx], 0, 0, 0);
                         }
                     }
@@ -192,6 +205,10 @@ __global__ __launch_bounds__(256, 1) void warp_gram_sparse_kernel(SparseParams p
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+    if (p.counters && lane == 0) {
+        atomicAdd(p.counters + 0, (unsigned long long)n_tiles * KS_HALF);
+        atomicAdd(p.counters + 1, (unsigned long long)n_blocks * KS_HALF);
+    }
     float *out = p.slab + ((long)b * p.nchunks + chunk) * SLAB;
     f32x4 *out4 = reinterpret_cast<f32x4 *>(out) + lane;
 #pragma unroll
@@ -295,7 +312,7 @@ size_t dnmf_warp_gram_rhs_sparse_workspace(long P, int K, int B) {
 int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask, int X,
                               int Y, int Z, const float *beta, int T, const int *times, int B, const float *frames,
                               long ldf, const int *frame_ids, float *G, float *r, void *workspace,
-                              size_t workspace_bytes, dnmf_stream_t stream) {
+                              size_t workspace_bytes, unsigned long long *counters, dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(Aps && order && row_mask && beta && frames && G && r && workspace, DNMF_E_NULL,
                  "dnmf_warp_gram_rhs_sparse: NULL buffer");
@@ -316,6 +333,7 @@ int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order,
     p.beta = beta, p.T = T, p.times = times, p.B = B;
     p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
     p.slab = static_cast<float *>(workspace);
+    p.counters = counters;
     sp_choose_chunks(p.vol.P, B, p.nchunks, p.chunk_len);
     hipStream_t st = (hipStream_t)stream;
     switch (Ks / 16) {

@@ -277,8 +277,13 @@ def pack_footprints_sparse(A, order):
     return Aps, mask
 
 
+# when bench.py sets TIMING it also finds here the executed-work counters of the K3s launches (int64[2] tensor)
+SPARSE_COUNTERS = None
+
+
 def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame_ids=None, workspace=None):
     """K3s.  Returns G (B,K,K), r (B,K) in the original neuron order."""
+    global SPARSE_COUNTERS
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
     dev = Aps.device
@@ -295,10 +300,15 @@ def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
     r = torch.empty((B, K), dtype=torch.float32, device=dev)
+    counters = None
+    if TIMING is not None:
+        if SPARSE_COUNTERS is None:
+            SPARSE_COUNTERS = torch.zeros(2, dtype=torch.int64, device=dev)
+        counters = SPARSE_COUNTERS
     with _timed("warp_gram_rhs_sparse"):
         rc = lib.dnmf_warp_gram_rhs_sparse(
             Aps.data_ptr(), Aps.shape[-1], K, od.data_ptr(), row_mask.data_ptr(), X, Y, Z, beta.data_ptr(),
             beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(),
-            workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream())
+            workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())
     _lib.check(rc, "dnmf_warp_gram_rhs_sparse")
     return G, r, workspace

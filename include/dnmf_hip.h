@@ -113,7 +113,9 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
  * which either factor is an exact zero is not evaluated, which changes no sum.
  * dnmf_pack_footprints_sparse: Aps (P,Ks) <- A[:, order], Ks = dnmf_sparse_k(K) = 16*ceil(K/16), zero padded;
  *   row_mask[p] bit b = row p has a non-zero among channels 16b..16b+15.  K <= 128.
- * dnmf_warp_gram_rhs_sparse: arguments as dnmf_warp_gram_rhs; G, r come out in the ORIGINAL neuron order. */
+ * dnmf_warp_gram_rhs_sparse: arguments as dnmf_warp_gram_rhs; G, r come out in the ORIGINAL neuron order.
+ *   counters: NULL, or 2 x uint64 that are INCREMENTED by the MFMA instructions issued and by the (block, k-step)
+ *   gathers executed (the work that was not skipped; bench.py's roofline uses them). */
 int dnmf_sparse_k(int K);
 int dnmf_pack_footprints_sparse(const float *A, long P, int K, const int *order, float *Aps, int Ks,
                                 unsigned char *row_mask, dnmf_stream_t stream);
@@ -121,7 +123,8 @@ size_t dnmf_warp_gram_rhs_sparse_workspace(long P, int K, int B);
 int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask,
                               int X, int Y, int Z, const float *beta, int T, const int *times, int B,
                               const float *frames, long ldf, const int *frame_ids, float *G, float *r,
-                              void *workspace, size_t workspace_bytes, dnmf_stream_t stream);
+                              void *workspace, size_t workspace_bytes, unsigned long long *counters,
+                              dnmf_stream_t stream);
 
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
