@@ -12,7 +12,7 @@
 
 namespace dnmf {
 
-constexpr int K2_VPT = 8;             // voxels per thread
+constexpr int K2_VPT = 16;            // voxels per thread
 constexpr int K2_VPB = 256 * K2_VPT;  // voxels per block
 constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
 
@@ -22,6 +22,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// HASZ = false is the Z == 1 specialisation: two coordinates, four taps, and only the six basis terms without z
+// (the other 18 gradient sums are identically zero and are written as such).
+template <bool HASZ>
 __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
                                                               const int *__restrict__ s_ids,
                                                               const float *__restrict__ frames, long ldf,
@@ -30,15 +33,20 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
                                                               const float *__restrict__ beta, int T,
                                                               const int *__restrict__ times,
                                                               float *__restrict__ recon, float *__restrict__ partial) {
+    constexpr int ND = HASZ ? 3 : 2;                 // warped coordinates that exist
+    constexpr int NA = HASZ ? 10 : 6;                // basis terms that are not identically zero
+    constexpr int BASIS_ID[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};  // z-free terms first
     const int b = blockIdx.y;
     const float *s = S + (long)(s_ids ? s_ids[b] : b) * lds;
     const float *y = frames ? frames + (long)(frame_ids ? frame_ids[b] : b) * ldf : nullptr;
     float bt[30];
     load_beta(beta, T, times[b], bt);
 
-    float acc[30];
+    float acc[NA][ND];
 #pragma unroll
-    for (int i = 0; i < 30; ++i) acc[i] = 0.0f;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) acc[a][d] = 0.0f;
     float sq = 0.0f;
     const int YZ = vol.Y * vol.Z;
 
@@ -47,10 +55,10 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
         if (p >= vol.P) break;
         int x, yy, z;
         voxel_xyz(p, vol, x, yy, z);
-        const Sample sm = make_sample(bt, vol, x, yy, z);
-        float rec = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
-        const int nz = vol.Z > 1 ? 2 : 1;
-        for (int dz = 0; dz < nz; ++dz) {
+        const Sample sm = make_sample_t<HASZ>(bt, vol, x, yy, z);
+        float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
             const int cz = sm.z0 + dz;
             const float wz = dz ? sm.wz1 : sm.wz0;
             const float sgz = dz ? 1.0f : -1.0f;
@@ -64,12 +72,18 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
                     const int cx = sm.x0 + dx;
                     const float wx = dx ? sm.wx1 : sm.wx0;
                     const float sgx = dx ? 1.0f : -1.0f;
-                    if (in_range(cx, vol.X) && in_range(cy, vol.Y) && in_range(cz, vol.Z)) {
-                        const float val = s[(long)cx * YZ + cy * vol.Z + cz];
-                        rec = fmaf(val, wx * wy * wz, rec);
-                        gx = fmaf(val, sgx * wy * wz, gx);
-                        gy = fmaf(val, wx * sgy * wz, gy);
-                        gz = fmaf(val, wx * wy * sgz, gz);
+                    if (in_range(cx, vol.X) && in_range(cy, vol.Y) && (!HASZ || in_range(cz, vol.Z))) {
+                        const float val = s[(long)cx * YZ + cy * vol.Z + (HASZ ? cz : 0)];
+                        if (HASZ) {
+                            rec = fmaf(val, wx * wy * wz, rec);
+                            g[0] = fmaf(val, sgx * wy * wz, g[0]);
+                            g[1] = fmaf(val, wx * sgy * wz, g[1]);
+                            g[2] = fmaf(val, wx * wy * sgz, g[2]);
+                        } else {
+                            rec = fmaf(val, wx * wy, rec);
+                            g[0] = fmaf(val, sgx * wy, g[0]);
+                            g[1] = fmaf(val, wx * sgy, g[1]);
+                        }
                     }
                 }
             }
@@ -79,27 +93,30 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
         const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
         sq = fmaf(resid, resid, sq);
         const float xf = (float)x, yf = (float)yy, zf = (float)z;
-        const float basis[10] = {1.0f, xf, yf, zf, xf * xf, yf * yf, zf * zf, xf * yf, xf * zf, yf * zf};
-        const float g0 = resid * gx, g1 = resid * gy, g2 = vol.Z > 1 ? resid * gz : 0.0f;
+        const float basis[10] = {1.0f, xf, yf, xf * xf, yf * yf, xf * yf, zf, zf * zf, xf * zf, yf * zf};
 #pragma unroll
-        for (int a = 0; a < 10; ++a) {
-            acc[a * 3 + 0] = fmaf(basis[a], g0, acc[a * 3 + 0]);
-            acc[a * 3 + 1] = fmaf(basis[a], g1, acc[a * 3 + 1]);
-            acc[a * 3 + 2] = fmaf(basis[a], g2, acc[a * 3 + 2]);
+        for (int d = 0; d < ND; ++d) {
+            const float gd = resid * g[d];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a][d] = fmaf(basis[a], gd, acc[a][d]);
         }
     }
 
     // block reduction: butterflies inside each wave, then the four wave leaders through LDS
     __shared__ float red[4][K2_NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < K2_NACC) red[wave][lane] = 0.0f;
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-        const float v = wave_sum(acc[i]);
-        if (lane == 0) red[wave][i] = v;
-    }
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float v = wave_sum(acc[a][d]);
+            if (lane == 0) red[wave][BASIS_ID[a] * 3 + d] = v;
+        }
     {
         const float v = wave_sum(sq);
-        if (lane == 0) red[wave][30] = v, red[wave][31] = 0.0f;
+        if (lane == 0) red[wave][30] = v;
     }
     __syncthreads();
     if (threadIdx.x < K2_NACC) {
@@ -198,8 +215,12 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
     float *partial = static_cast<float *>(workspace);
     float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(warp_recon_grad_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds, s_ids,
-                       frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
+    if (Z > 1)
+        hipLaunchKernelGGL(warp_recon_grad_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds,
+                           s_ids, frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
+    else
+        hipLaunchKernelGGL(warp_recon_grad_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds,
+                           s_ids, frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
     if (norm_frames <= 0) norm_frames = B;
     const float grad_scale = gout ? 1.0f : 2.0f / ((float)norm_frames * (float)vol.P);
     hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T,
