@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
         unsigned m = 0;
         {
             const long v = v_begin + (long)s * KS_SS + lane;
-            unsigned rows[NTAP];
+            unsigned rows[NTAP], voxs[NTAP];
             float w[NTAP];
             float yv = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
+            for (int c = 0; c < NTAP; ++c) rows[c] = 0u, voxs[c] = 0u, w[c] = 0.0f;
             if (v < v_end) {
                 int x, y, z;
                 voxel_xyz(v, vol, x, y, z);
@@ -129,10 +129,16 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
                         vox = vox * (unsigned)vol.Z + (unsigned)cz;
                     }
                     w[c] = ok ? wc : 0.0f;
-                    rows[c] = ok ? vox * row_bytes : 0u;
-                    if (ok) m |= p.row_mask[vox];
+                    voxs[c] = ok ? vox : 0u;
+                    rows[c] = voxs[c] * row_bytes;
                 }
                 yv = yb[v];
+                // all mask bytes requested together (one round trip); a tap without weight contributes no block
+                unsigned mk[NTAP];
+#pragma unroll
+                for (int c = 0; c < NTAP; ++c) mk[c] = p.row_mask[voxs[c]];
+#pragma unroll
+                for (int c = 0; c < NTAP; ++c) m |= (w[c] != 0.0f) ? mk[c] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
