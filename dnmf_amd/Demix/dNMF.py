@@ -47,7 +47,7 @@ class _WarpRecon(torch.autograd.Function):
     def forward(ctx, beta, fp, times, C):
         times_t = torch.as_tensor(list(times), dtype=torch.int32, device=beta.device)
         Csel = C.to(device=beta.device, dtype=torch.float32).contiguous()
-        S = ops.recon_image(fp.packed_footprints(), fp.K, Csel, times_t)
+        S = fp.recon_image(Csel, times_t)
         out = ops.warp_recon_grad(S, None, None, None, fp.sz_list, beta.detach(), times_t, grad=None,
                                   gout=torch.zeros((len(times_t), fp.P), dtype=torch.float32, device=beta.device),
                                   want_recon=True, want_loss=False, want_reg=True)
@@ -125,6 +125,26 @@ class ExponentialFP(nn.Module):
             self._packed = ops.pack_footprints(self.A.contiguous())
             self._packed_version = key
         return self._packed
+
+    def packed_columns(self, cols):
+        """Packed copy of the footprints of the neurons ``cols`` only (K > 127 is handled by column groups: the MFMA
+        kernels hold at most 8 blocks of 16 channels in registers)."""
+        sub = self.A.reshape(self.P, self.K)[:, torch.as_tensor(cols, device=self.A.device)].contiguous()
+        return ops.pack_footprints(sub)
+
+    def recon_image(self, C, times, out=None):
+        """S[b] = A . C[:, times[b]] (``dnmf_recon_image``), by groups of 112 neurons when K > 127."""
+        if self.K <= 127:
+            return ops.recon_image(self.packed_footprints(), self.K, C, times, out=out)
+        for n, s0 in enumerate(range(0, self.K, 112)):
+            cols = list(range(s0, min(self.K, s0 + 112)))
+            part = ops.recon_image(self.packed_columns(cols), len(cols), C[cols].contiguous(), times,
+                                   out=out if n == 0 else None)
+            if n == 0:
+                out = part
+            else:
+                out[:part.shape[0]] += part
+        return out
 
     def packed_sparse(self):
         """Layout for the zero-skipping Gram kernel K3s: neurons ordered along a Z-order curve of their footprint
@@ -242,8 +262,12 @@ class DeformableNMF:
         Y_dev = torch.from_numpy(np.ascontiguousarray(Y_i.reshape(-1, T).T)).to(dev, torch.float32)
         C_dev = torch.from_numpy(np.ascontiguousarray(C)).to(dev, torch.float32)
         D_dev = None if D is None else torch.from_numpy(np.ascontiguousarray(np.asarray(D).reshape(-1, K))).to(dev, torch.float32)
-        A1, Cs = ops.spatial_accum(Y_dev, C_dev)
-        ops.mu_spatial(A_dev, A1, Cs, D_dev, gamma)
+        if K <= 128:
+            A1, Cs = ops.spatial_accum(Y_dev, C_dev)
+        else:  # K5 holds 8 trace blocks per wave: columns of A1 by groups; C C^T is tiny
+            A1 = torch.cat([ops.spatial_accum(Y_dev, C_dev[s0:s0 + 128].contiguous())[0] for s0 in range(0, K, 128)], 1)
+            Cs = (C_dev.double() @ C_dev.double().T).float()
+        ops.mu_spatial(A_dev, A1.contiguous(), Cs, D_dev, gamma)
         return A_dev.double().cpu().numpy().reshape(A.shape)
 
     # ---- fit steps -------------------------------------------------------------------------------------
@@ -296,6 +320,8 @@ class DeformableNMF:
     def _gram_rhs(self, frames, order):
         """Per-frame Gram matrices and right-hand sides under the current warp (K3 or K3s)."""
         fp = self.fp
+        if fp.K > 127:
+            return self._gram_rhs_grouped(frames, order)
         sp = fp.packed_sparse() if self.gram_kernel in ('auto', 'sparse') else None
         if sp is not None and (self.gram_kernel == 'sparse' or sp["occupancy"] < 0.5):
             G, r, self._ws_k3 = ops.warp_gram_rhs_sparse(sp["Aps"], fp.K, sp["order"], sp["row_mask"], fp.sz_list,
@@ -303,6 +329,25 @@ class DeformableNMF:
         else:
             G, r, self._ws_k3 = ops.warp_gram_rhs(fp.packed_footprints(), fp.K, fp.sz_list, fp.beta.detach(), order,
                                                   frames, workspace=self._ws_k3)
+        return G, r
+
+    def _gram_rhs_grouped(self, frames, order, group=56):
+        """K > 127: the Gram kernel holds at most 112 channels, so neurons are cut into groups of 56 and every PAIR
+        of groups is one K3 launch on their union; the launch yields both diagonal blocks and the off-diagonal
+        block of the pair (diagonal blocks are recomputed by every pair they belong to)."""
+        fp = self.fp
+        K, B = fp.K, order.numel()
+        groups = [list(range(s0, min(K, s0 + group))) for s0 in range(0, K, group)]
+        G = torch.empty((B, K, K), dtype=torch.float32, device=device)
+        r = torch.empty((B, K), dtype=torch.float32, device=device)
+        for i in range(len(groups)):
+            for j in range(i + 1, len(groups)):
+                cols = groups[i] + groups[j]
+                Gp, rp, self._ws_k3 = ops.warp_gram_rhs(fp.packed_columns(cols), len(cols), fp.sz_list, fp.beta.detach(),
+                                                        order, frames, workspace=self._ws_k3)
+                idx = torch.as_tensor(cols, device=device)
+                G[:, idx[:, None], idx[None, :]] = Gp
+                r[:, idx] = rp
         return G, r
 
     def _recon_cache(self, frame_ids=None):
@@ -315,7 +360,7 @@ class DeformableNMF:
         C = self.C.to(device, torch.float32).contiguous()
         all_t = torch.arange(fp.T, dtype=torch.int32, device=device)
         for s in range(0, fp.T, 32768):
-            ops.recon_image(fp.packed_footprints(), fp.K, C, all_t[s:s + 32768], out=S[s:s + 32768])
+            fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768])
         return S
 
     def update_motion(self, dataloader, optimizer, gamma=0, epochs=20):
@@ -344,7 +389,7 @@ class DeformableNMF:
                 if S_all is not None:
                     S, s_ids = S_all, times
                 else:
-                    S, s_ids = ops.recon_image(fp.packed_footprints(), fp.K, Cdev, times), None
+                    S, s_ids = fp.recon_image(Cdev, times), None
                 want = self.verbose and batch_idx % 10 == 0
                 out = ops.warp_recon_grad(S, s_ids, frames, frame_ids, fp.sz_list, beta.detach(), times,
                                           grad=beta.grad, want_loss=want, want_reg=want, workspace=self._ws_k2,

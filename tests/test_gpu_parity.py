@@ -479,3 +479,42 @@ def test_sparse_gram_full_size(M):
     assert float((Gs - Gd).abs().max()) < 2e-6 * float(Gd.abs().max())
     assert float((rs - rd).abs().max()) < 2e-6 * float(rd.abs().max())
     assert 0.05 < sp["occupancy"] < 0.5
+
+
+@pytest.mark.parametrize("K", [130, 200])
+def test_more_than_127_neurons(M, O, K):
+    """BASELINE config 5's K=200: Gram by pairs of neuron groups, recon image by groups, through the fit steps."""
+    rng = np.random.RandomState(K)
+    sz, T, bs = [28, 24, 2], 6, 3
+    pos = rng.rand(K, 3) * np.array(sz)
+    video = np.maximum(rng.rand(*sz, T).astype(np.float32) - 0.2, 0)
+    C0 = rng.rand(K, T).astype(np.float32)
+    beta0 = O.identity_beta(T) + (rng.randn(10, 3, T) * np.array([0.5, 5e-3, 5e-3, 5e-3, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4]
+                                                                  )[:, None, None]).astype(np.float32)
+    ref = O.OracleModel(sz, K, T, pos, C0=C0)
+    with torch.no_grad():
+        ref.beta_param.copy_(torch.from_numpy(beta0))
+    ropt = torch.optim.Adam([ref.beta_param], lr=1e-3)
+    batches = [list(range(s0, s0 + bs)) for s0 in range(0, T, bs)]
+    ref.update_motion(video, batches, ropt, gamma=1, epochs=1)
+    ref.update_footprints(video, bs, gamma_c=0, iter_c=6)
+
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+    dn.verbose = False
+    dn.fp.A = dev(ref.A)
+    dn.C = dev(C0)
+    with torch.no_grad():
+        dn.fp.beta.copy_(dev(beta0))
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+    frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(video, 3, 0)))
+    loader = [(frames[b], torch.tensor(b)) for b in batches]
+    dn.update_motion(loader, opt, gamma=1, epochs=1)
+    dn.update_footprints(loader, bs, sz, gamma_c=0, iter_c=6, return_dense=False)
+    disp = np.abs(ref.beta - beta0).max()
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - beta0, ref.beta - beta0, rtol=0, atol=2e-3 * disp)
+    np.testing.assert_allclose(dn.C.cpu().numpy(), ref.C, rtol=2e-4, atol=1e-7)
+    # static update_spatial with K > 128
+    A = rng.rand(9, 7, K)
+    Cc = rng.rand(K, 11)
+    Yi = rng.rand(9, 7, 11)
+    np.testing.assert_allclose(M.DeformableNMF.update_spatial(A, Cc, Yi), O.update_spatial(A, Cc, Yi), rtol=2e-5)
