@@ -518,3 +518,45 @@ def test_more_than_127_neurons(M, O, K):
     Cc = rng.rand(K, 11)
     Yi = rng.rand(9, 7, 11)
     np.testing.assert_allclose(M.DeformableNMF.update_spatial(A, Cc, Yi), O.update_spatial(A, Cc, Yi), rtol=2e-5)
+
+
+def test_config1_like_run_vs_oracle(M, O):
+    """BASELINE configs[0] geometry (64x64, K=10, simulator video) for two outer iterations of the demo loop with
+    shuffled mini-batches, against the CPU oracle run on the same batch order."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sz, K, T, bs = [64, 64, 2], 10, 24, 4
+    video, positions, _ = O.generate_video(K, T, sz, 3, .2, -120, {"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    video = np.maximum(video, 0)
+    C0 = torch.rand(K, T)
+    gen = torch.Generator().manual_seed(3)
+    orders = [[torch.randperm(T, generator=gen).tolist() for _ in range(2)] for _ in range(2)]
+    ref = O.OracleModel(sz, K, T, positions[:, :, 0], C0=C0.numpy())
+    ropt = torch.optim.Adam([ref.beta_param], lr=1e-4)
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(positions[:, :, 0]))
+    dn.verbose = False
+    dn.fp.A = dev(ref.A)
+    dn.C = C0.to("cuda")
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-4)
+    frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(video, 3, 0)))
+    test = [(frames[s0:s0 + bs], torch.arange(s0, s0 + bs)) for s0 in range(0, T, bs)]
+    for outer in range(2):
+        for perm in orders[outer]:
+            batches = [perm[s0:s0 + bs] for s0 in range(0, T, bs)]
+            ref.update_motion(video, batches, ropt, gamma=1, epochs=1)
+            dn.update_motion([(frames[b], torch.tensor(b)) for b in batches], opt, gamma=1, epochs=1)
+        ref.update_footprints(video, bs, gamma_c=0, iter_c=10)
+        dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=10, return_dense=False)
+    ident = O.identity_beta(T)
+    disp = np.abs(ref.beta - ident).max()
+    # on-lattice ambiguity after the first Adam step (see the fused-epoch test) limits beta to a few 1e-3 of a step
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - ident, ref.beta - ident, rtol=0, atol=1e-2 * disp)
+    # At these settings the reference's own multiplicative update runs away for most neurons (the CPU oracle ends
+    # with row maxima from 0.5 up to 1e24: c*r/(Gc + 1e-32) with G_kk ~ 0 for footprints at or beyond the border),
+    # and a runaway row amplifies any rounding difference.  Rows that stay bounded must agree tightly; runaway rows
+    # must run away here too.
+    got, want = dn.C.cpu().numpy(), ref.C
+    calm = want.max(1) < 10
+    assert calm.sum() >= 3
+    np.testing.assert_allclose(got[calm], want[calm], rtol=5e-3, atol=1e-6)  # beta of one frame differs by the lattice tie
+    assert np.all(got[~calm].max(1) > 10)
