@@ -537,12 +537,29 @@ class ResidentLoader:
 class SimulatedVideoDataset(Dataset):
     """Reference ``Demix/dNMF.py:196-217``: a synthetic video and its ground truth."""
 
-    def __init__(self, K, T, sz, shape_std, density, bg_snr, traces, motion, motion_par):
-        video, positions, traces = Simulator.generate_video(K, T, _sz_list(sz), shape_std, density, bg_snr, traces,
-                                                            motion, motion_par)
+    def __init__(self, K, T, sz, shape_std, density, bg_snr, traces, motion, motion_par, resident=False):
+        """``resident=True`` (extension) renders the video on the GPU (``dnmf_render_frames``) and keeps it there,
+        frame-major; ``video`` is then a CUDA view of shape (X,Y,Z,T) and ``loader()`` hands the rows to the fit
+        steps without copies.  The noise is then drawn by the device generator, not the CPU one."""
+        if resident:
+            if traces != 'exp' or motion != 'gp':
+                raise NotImplementedError("only traces='exp', motion='gp' are available")
+            frames, positions, traces = Simulator.generate_video_resident(K, T, _sz_list(sz), shape_std, density, bg_snr,
+                                                                          motion_par, device=device)
+            video = frames.view(T, *_sz_list(sz)).permute(1, 2, 3, 0)
+        else:
+            video, positions, traces = Simulator.generate_video(K, T, _sz_list(sz), shape_std, density, bg_snr, traces,
+                                                                motion, motion_par)
         self.video = video.float()
         self.positions = positions
         self.traces = traces
+        self._sz = _sz_list(sz)
+
+    def loader(self, batch_size, shuffle=False, generator=None):
+        """A ResidentLoader over this video (clamped at 0 like ``__getitem__`` does frame by frame)."""
+        frames = self.video.permute(3, 0, 1, 2).reshape(self.video.shape[3], -1)
+        frames = frames.to(device).clamp_(min=0)
+        return ResidentLoader(frames, self._sz, batch_size, shuffle=shuffle, generator=generator)
 
     def __len__(self):
         return self.video.shape[3]

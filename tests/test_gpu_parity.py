@@ -560,3 +560,20 @@ def test_config1_like_run_vs_oracle(M, O):
     assert calm.sum() >= 3
     np.testing.assert_allclose(got[calm], want[calm], rtol=5e-3, atol=1e-6)  # beta of one frame differs by the lattice tie
     assert np.all(got[~calm].max(1) > 10)
+
+
+def test_resident_dataset_and_loader(M):
+    """SimulatedVideoDataset(resident=True) + .loader(): the whole fit without a host copy of the video."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sz, K, T = torch.tensor([40, 32, 2]), 6, 16
+    ds = M.SimulatedVideoDataset(K=K, T=T, sz=sz, shape_std=3, density=.2, bg_snr=-120, traces='exp', motion='gp',
+                                 motion_par={'sigma': [5, 5, .01], 'ls': [10, 10, 10]}, resident=True)
+    assert ds.video.is_cuda and tuple(ds.video.shape) == (40, 32, 2, T) and len(ds) == T
+    dn = M.DeformableNMF(sz, K, T, positions=ds.positions[:, :, 0])
+    dn.verbose = False
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
+    dn.update_motion(ds.loader(4, shuffle=True, generator=torch.Generator().manual_seed(0)), opt, gamma=1, epochs=2)
+    A_t, Y_i, Y = dn.update_footprints(ds.loader(4), 4, sz, gamma_c=0, iter_c=5)
+    assert A_t.shape == (40, 32, 2, K, T) and np.isfinite(dn.C.cpu().numpy()).all()
+    np.testing.assert_allclose(Y, np.maximum(ds.video.double().cpu().numpy(), 0), rtol=0, atol=0)

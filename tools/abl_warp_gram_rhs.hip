@@ -26,7 +26,7 @@
 // pass), parked in wave-private LDS and re-read as broadcasts by the 16 lanes that share the voxel.
 // The fp32 sequence for the coordinates is common.hpp's (bit-compatible with the reference's
 // normalise / grid_sample un-normalise round trip).
-#include "common.hpp"
+#include "../dnmf_amd/csrc/common.hpp"
 
 namespace dnmf {
 
@@ -205,18 +205,25 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         for (int q = 0; q < NQ; ++q) {
             st.w[q] = rc.w[q];
 #pragma unroll
+#if ABL == 2
+            load_row<NB>(st.raw[4 * q], Ab, rc.rr[q][0] + lane_a, rc.rr[q][0] + lane_b);
+            for (int e = 1; e < 4; ++e) st.raw[4 * q + e] = st.raw[4 * q];
+#else
             for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rc.rr[q][e] + lane_a, rc.rr[q][e] + lane_b);
+#endif
         }
         st.y = rc.y;
     };
     auto blend = [&](const Stage &st, float (&frag)[NB]) {
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) frag[bb] = st.raw[0].v[bb] * st.w[0][0];
+#if ABL != 1
 #pragma unroll
         for (int c = 1; c < NTAP; ++c) {
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) frag[bb] = fmaf(st.raw[c].v[bb], st.w[c >> 2][c & 3], frag[bb]);
         }
+#endif
         frag[NB - 1] = ylane ? st.y : frag[NB - 1];
     };
     auto mfmas = [&](const float (&frag)[NB]) {
@@ -240,17 +247,13 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         __builtin_amdgcn_sched_barrier(0);
         issue(rec, st_req);
         fetch_rec(kk_req + 1, rec);
+        __builtin_amdgcn_sched_barrier(0);
         blend(st_next, f_next);
         mfmas(f_cur);
-        // One stream: the row requests are spread over the MFMAs instead of being issued as a burst (a vector-memory
-        // instruction occupies the wave for ~30 cycles when eight waves of a CU issue theirs at the same moment),
-        // address adds and the blend fill the remaining vector slots.
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NQ + 1, 0);  // the next record (LDS reads)
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address adds, then the blend
-            if (i % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one row request
+            __builtin_amdgcn_sched_group_barrier(0x002, NTAP / 4, 0);  // VALU of the blend
         }
         __builtin_amdgcn_sched_barrier(0);
     };
