@@ -570,3 +570,32 @@ class SimulatedVideoDataset(Dataset):
         sample = self.video[:, :, :, idx]
         sample[sample < 0] = 0  # in place on the stored video, like the reference (:214-215)
         return sample, idx
+
+
+class NeuroPALVideoDataset(Dataset):
+    """Reference ``Demix/dNMF.py:220-248``: a recorded video (``data.mat``: ``data`` (X,Y,Z,T)) with tracked
+    neuron positions (``traces_n.mat``: ``positions`` (K,3,T), 1-based; ``neuron_names``).  Same fixed
+    sub-sampling as the reference (every 2nd voxel in x and y, every 10th in z, the first 100 frames); paths are
+    joined portably (the reference hard-codes Windows separators)."""
+
+    def __init__(self, file):
+        import os
+        from scipy.io import loadmat
+        vid_mat = loadmat(os.path.join(file, 'data.mat'))
+        self.video = np.array(vid_mat['data'][::2, ::2, ::10, :100]).astype(np.float32)
+        pos_mat = loadmat(os.path.join(file, 'traces_n.mat'))
+        self.positions = torch.tensor(pos_mat['positions']).float() - 1
+        self.positions[:, 0, :] /= 2
+        self.positions[:, 1, :] /= 2
+        self.positions[:, 2, :] /= 10
+        self.names = pos_mat['neuron_names'][0]
+
+    def __len__(self):
+        return self.video.shape[3]
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        sample = self.video[:, :, :, idx]
+        sample[sample < 0] = 0
+        return sample, idx

@@ -113,3 +113,20 @@ def test_dataset_protocol_and_in_place_clamp():
     loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
     batch = next(iter(loader))
     assert tuple(batch[0].shape) == (4, 16, 16, 2) and batch[1].tolist() == [0, 1, 2, 3]
+
+
+def test_neuropal_dataset_reads_mat_files(tmp_path):
+    """The real-data loader of the reference (its data is not in the tree): round trip through scipy's .mat files."""
+    from scipy.io import savemat
+    from dnmf_amd.Demix.dNMF import NeuroPALVideoDataset
+    rng = np.random.RandomState(0)
+    data = rng.randn(12, 10, 20, 5)
+    pos = 1 + rng.rand(4, 3, 5) * np.array([12, 10, 20])[None, :, None]
+    savemat(tmp_path / "data.mat", {"data": data})
+    savemat(tmp_path / "traces_n.mat", {"positions": pos, "neuron_names": np.array([["a", "b", "c", "d"]], dtype=object)})
+    ds = NeuroPALVideoDataset(str(tmp_path))
+    assert len(ds) == 5 and ds.video.shape == (6, 5, 2, 5) and tuple(ds.positions.shape) == (4, 3, 5)
+    np.testing.assert_allclose(ds.positions[:, 0].numpy(), (pos[:, 0] - 1) / 2, rtol=1e-6)
+    np.testing.assert_allclose(ds.positions[:, 2].numpy(), (pos[:, 2] - 1) / 10, rtol=1e-6)
+    frame, idx = ds[3]
+    assert idx == 3 and frame.min() >= 0 and frame.shape == (6, 5, 2)
