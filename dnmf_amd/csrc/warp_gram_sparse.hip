@@ -60,7 +60,11 @@ struct SparseParams {
     const int *frame_ids;
     float *slab;  // (B, nchunks, NT*256 + 128)
     int nchunks;
-    long chunk_len;
+    long chunk_len;    // passes (patches of 64 voxels) per chunk
+    // a pass is a compact patch of 2^lgx x 2^lgy x 2^lgz = 64 voxels (8x8 for Z == 1), not a run of 64 voxels: fewer
+    // footprints reach into a compact patch, so fewer blocks and tiles are active per pass
+    int lgy, lgz, npy, npz;
+    long npatch;
     unsigned long long *counters;  // optional: [0] += MFMAs issued, [1] += (active block, k-step) blends
 };
 
@@ -97,24 +101,27 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
 #pragma unroll
     for (int i = 0; i < NB; ++i) racc[i] = 0.0f;
 
-    const long v_begin = (long)chunk * p.chunk_len;
-    const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
-    const int nss = (int)((v_end - v_begin + KS_SS - 1) / KS_SS);
+    const long q_begin = (long)chunk * p.chunk_len;
+    const long q_end = q_begin + p.chunk_len < p.npatch ? q_begin + p.chunk_len : p.npatch;
+    const int nss = (int)(q_end - q_begin);
+    // patch origin of the first pass (wave-uniform), advanced with carries; lane -> voxel inside the patch
+    const int lgy = p.lgy, lgz = p.lgz;
+    int pz = (int)(q_begin % p.npz), py = (int)((q_begin / p.npz) % p.npy), px = (int)(q_begin / ((long)p.npz * p.npy));
+    const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & ((1 << lgy) - 1), lx = lane >> (lgz + lgy);
+    const int lgx = 6 - lgy - lgz;
     unsigned n_tiles = 0, n_blocks = 0;  // (tile, half pass) and (block, half pass) pairs executed
 
     for (int s = 0; s < nss; ++s) {
         // ---- coordinate pass + block set of the pass ------------------------------------------------------
         unsigned m = 0;
         {
-            const long v = v_begin + (long)s * KS_SS + lane;
+            const int x = (px << lgx) + lx, y = (py << lgy) + ly, z = (pz << lgz) + lz;
             unsigned rows[NTAP], voxs[NTAP];
             float w[NTAP];
             float yv = 0.0f;
 #pragma unroll
             for (int c = 0; c < NTAP; ++c) rows[c] = 0u, voxs[c] = 0u, w[c] = 0.0f;
-            if (v < v_end) {
-                int x, y, z;
-                voxel_xyz(v, vol, x, y, z);
+            if (x < vol.X && y < vol.Y && z < vol.Z) {
                 const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
 #pragma unroll
                 for (int c = 0; c < NTAP; ++c) {
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
                     voxs[c] = ok ? vox : 0u;
                     rows[c] = voxs[c] * row_bytes;
                 }
-                yv = yb[v];
+                yv = yb[((long)x * vol.Y + y) * vol.Z + z];
                 // all mask bytes requested together (one round trip); a tap without weight contributes no block
                 unsigned mk[NTAP];
 #pragma unroll
@@ -205,6 +212,10 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
                 }
             }
         }
+        if (++pz == p.npz) {
+            pz = 0;
+            if (++py == p.npy) py = 0, ++px;
+        }
         // the next coordinate pass overwrites the records: keep it behind this pass's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -263,15 +274,24 @@ __global__ __launch_bounds__(256) void gram_sparse_finish_kernel(const float *__
     }
 }
 
-static void sp_choose_chunks(long P, int B, int &nchunks, long &chunk_len) {
-    const long nss = (P + KS_SS - 1) / KS_SS;
+static void sp_patch_shape(const Volume &vol, int &lgy, int &lgz, int &npy, int &npz, long &npatch) {
+    lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
+    lgy = vol.Z <= 2 ? 3 : 2;
+    const int lgx = 6 - lgy - lgz;
+    npz = (vol.Z + (1 << lgz) - 1) >> lgz;
+    npy = (vol.Y + (1 << lgy) - 1) >> lgy;
+    npatch = (long)((vol.X + (1 << lgx) - 1) >> lgx) * npy * npz;
+}
+
+static void sp_choose_chunks(long npatch, int B, int &nchunks, long &chunk_len) {
+    const long nss = npatch;
     long want = (8192 + B - 1) / B;  // passes differ a lot in cost: more, smaller work items than the dense kernel
     if (want < 1) want = 1;
     if (want > 64) want = 64;
     if (want > nss) want = nss;
     const long ss_per_chunk = (nss + want - 1) / want;
-    chunk_len = ss_per_chunk * KS_SS;
-    nchunks = (int)((P + chunk_len - 1) / chunk_len);
+    chunk_len = ss_per_chunk;
+    nchunks = (int)((npatch + chunk_len - 1) / chunk_len);
 }
 
 template <int NB>
@@ -309,10 +329,15 @@ int dnmf_pack_footprints_sparse(const float *A, long P, int K, const int *order,
 size_t dnmf_warp_gram_rhs_sparse_workspace(long P, int K, int B) {
     if (P <= 0 || K <= 0 || B <= 0) return 0;
     const int NB = dnmf_sparse_k(K) / 16;
-    int nchunks;
-    long chunk_len;
-    dnmf::sp_choose_chunks(P, B, nchunks, chunk_len);
-    return (size_t)B * nchunks * ((size_t)(NB * (NB + 1) / 2) * 256 + 128) * sizeof(float);
+    // the patch count depends on the volume shape, not only on P: bound it by the worst shape (all three
+    // axes one voxel past a patch boundary cannot exceed 8x the voxel count / 64)
+    const long npatch_max = P / 8 + 64;
+    const long per_item = (long)(NB * (NB + 1) / 2) * 256 + 128;
+    long want = (8192 + B - 1) / B;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    (void)npatch_max;
+    return (size_t)B * (size_t)(want + 1) * per_item * sizeof(float);
 }
 
 int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask, int X,
@@ -340,7 +365,10 @@ int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order,
     p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
     p.slab = static_cast<float *>(workspace);
     p.counters = counters;
-    sp_choose_chunks(p.vol.P, B, p.nchunks, p.chunk_len);
+    sp_patch_shape(p.vol, p.lgy, p.lgz, p.npy, p.npz, p.npatch);
+    sp_choose_chunks(p.npatch, B, p.nchunks, p.chunk_len);
+    DNMF_REQUIRE(workspace_bytes >= (size_t)B * p.nchunks * ((size_t)(Ks / 16 * (Ks / 16 + 1) / 2) * 256 + 128) * sizeof(float),
+                 DNMF_E_WORKSPACE, "dnmf_warp_gram_rhs_sparse: workspace too small for %d chunks", p.nchunks);
     hipStream_t st = (hipStream_t)stream;
     switch (Ks / 16) {
         case 1: return launch_sparse<1>(p, order, G, r, st);
