@@ -86,7 +86,11 @@ struct GramParams {
     const int *frame_ids;
     float *slab;       // (B, nchunks, NT, 64, 4)
     int nchunks;
-    long chunk_len;    // voxels per chunk, multiple of K3_SS
+    long chunk_len;    // passes (patches of 64 voxels) per chunk
+    // a pass is a compact patch of 2^lgx x 2^lgy x 2^lgz = 64 voxels (8x8 for Z == 1): its gathers touch ~80
+    // distinct footprint rows instead of the ~130 of a 64-voxel run, so more of them hit in L1
+    int lgy, lgz, npy, npz;
+    long npatch;
 };
 
 // NTAP = 4 (Z == 1, bilinear) or 8 (trilinear).  Tap c: dx = c&1, dy = (c>>1)&1, dz = c>>2 (ATen's corner order).
@@ -129,22 +133,29 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const long v_begin = (long)chunk * p.chunk_len;
-    const long v_end = v_begin + p.chunk_len < vol.P ? v_begin + p.chunk_len : vol.P;
-    const int nss = (int)((v_end - v_begin + K3_SS - 1) / K3_SS);
+    const long q_begin = (long)chunk * p.chunk_len;
+    const long q_end = q_begin + p.chunk_len < p.npatch ? q_begin + p.chunk_len : p.npatch;
+    const int nss = (int)(q_end - q_begin);
     const int nk = nss * (K3_SS / 4);
+    // patch origin of the next coordinate pass (wave-uniform, advanced with carries); lane -> voxel in the patch
+    const int lgy = p.lgy, lgz = p.lgz, lgx = 6 - lgy - lgz;
+    int pz = (int)(q_begin % p.npz), py = (int)((q_begin / p.npz) % p.npy), px = (int)(q_begin / ((long)p.npz * p.npy));
+    const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & ((1 << lgy) - 1), lx = lane >> (lgz + lgy);
 
-    // coordinate pass s: lane -> voxel v_begin + 64 s + lane, record into LDS buffer s & 1
+    // coordinate pass s (called for s = 0, 1, 2, ... in order): lane -> one voxel of patch q_begin + s, record into
+    // LDS buffer s & 1
     auto coord_pass = [&](int s) {
-        const long v = v_begin + (long)s * K3_SS + lane;
+        const int x = (px << lgx) + lx, y = (py << lgy) + ly, z = (pz << lgz) + lz;
+        if (++pz == p.npz) {
+            pz = 0;
+            if (++py == p.npy) py = 0, ++px;
+        }
         unsigned rows[NTAP];
         float w[NTAP];
         float yv = 0.0f;
 #pragma unroll
         for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
-        if (v < v_end) {
-            int x, y, z;
-            voxel_xyz(v, vol, x, y, z);
+        if (x < vol.X && y < vol.Y && z < vol.Z) {
             const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
 #pragma unroll
             for (int c = 0; c < NTAP; ++c) {
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
                 w[c] = ok ? wc : 0.0f;
                 rows[c] = ok ? vox * row_bytes : 0u;
             }
-            yv = yb[v];
+            yv = yb[((long)x * vol.Y + y) * vol.Z + z];
         }
         const int buf = s & 1;
 #pragma unroll
@@ -314,15 +325,24 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
     }
 }
 
-static void choose_chunks(long P, int B, int &nchunks, long &chunk_len) {
-    const long nss = (P + K3_SS - 1) / K3_SS;  // coordinate passes per frame
+static void patch_shape(const Volume &vol, int &lgy, int &lgz, int &npy, int &npz, long &npatch) {
+    lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
+    lgy = vol.Z <= 2 ? 3 : 2;
+    const int lgx = 6 - lgy - lgz;
+    npz = (vol.Z + (1 << lgz) - 1) >> lgz;
+    npy = (vol.Y + (1 << lgy) - 1) >> lgy;
+    npatch = (long)((vol.X + (1 << lgx) - 1) >> lgx) * npy * npz;
+}
+
+static void choose_chunks(long npatch, int B, int &nchunks, long &chunk_len) {
+    const long nss = npatch;  // coordinate passes per frame
     long want = (4096 + B - 1) / B;            // aim for >= 4096 wave-sized work items
     if (want < 1) want = 1;
     if (want > 64) want = 64;
     if (want > nss) want = nss;
     const long ss_per_chunk = (nss + want - 1) / want;
-    chunk_len = ss_per_chunk * K3_SS;
-    nchunks = (int)((P + chunk_len - 1) / chunk_len);
+    chunk_len = ss_per_chunk;
+    nchunks = (int)((npatch + chunk_len - 1) / chunk_len);
 }
 
 template <int NB>
@@ -344,10 +364,10 @@ extern "C" {
 size_t dnmf_warp_gram_rhs_workspace(long P, int K, int B) {
     if (P <= 0 || K <= 0 || B <= 0) return 0;
     const int NB = dnmf_padded_k(K) / 16;
-    int nchunks;
-    long chunk_len;
-    dnmf::choose_chunks(P, B, nchunks, chunk_len);
-    return (size_t)B * nchunks * (NB * (NB + 1) / 2) * 256 * sizeof(float);
+    long want = (4096 + B - 1) / B;  // upper bound of the chunk count chosen at launch (it depends on the shape)
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    return (size_t)B * (size_t)(want + 1) * (NB * (NB + 1) / 2) * 256 * sizeof(float);
 }
 
 int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z, const float *beta,
@@ -373,7 +393,8 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
     p.beta = beta, p.T = T, p.times = times, p.B = B;
     p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
     p.slab = static_cast<float *>(workspace);
-    choose_chunks(p.vol.P, B, p.nchunks, p.chunk_len);
+    patch_shape(p.vol, p.lgy, p.lgz, p.npy, p.npz, p.npatch);
+    choose_chunks(p.npatch, B, p.nchunks, p.chunk_len);
     hipStream_t st = (hipStream_t)stream;
     switch (Kp / 16) {
         case 1: return launch_gram<1>(p, G, r, st);

@@ -53,7 +53,7 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert rc == -3
     rc = lib.dnmf_warp_gram_rhs(addr, 16, 3, 0, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr, 8, None)
     assert rc in (-2, -4)  # alignment or workspace, never a launch
-    assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 2 * 28 * 256 * 4
+    assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 3 * 28 * 256 * 4
 
 
 def test_product_has_no_cpu_fallback():
