@@ -49,10 +49,32 @@ def plan_epoch(perm: torch.Tensor, batch_size: int, t0: int, t1: int) -> EpochPl
         size_of_step[-1] = n_total % batch_size
     mine = (perm >= t0) & (perm < t1)
     local = perm[mine] - t0
-    steps = step_of_pos[mine]
+    steps = step_of_pos[mine]            # non-decreasing: positions are visited in order
     frame_step = torch.full((t1 - t0,), -1, dtype=torch.int32)
     frame_step[local] = steps.to(torch.int32)
     sizes = size_of_step[steps]
-    groups = [(local[sizes == s], int(s)) for s in sorted(set(sizes.tolist()), reverse=True)]
-    batches = [local[steps == j] for j in range(nsteps)]
-    return EpochPlan(nsteps=nsteps, frame_step=frame_step, groups=groups, batches=batches)
+    groups = [(local[sizes == s], int(s)) for s in sorted(set(size_of_step.tolist()), reverse=True)]
+    groups = [g for g in groups if g[0].numel()]
+    counts = torch.bincount(steps, minlength=nsteps).tolist()
+    return EpochPlan(nsteps=nsteps, frame_step=frame_step, groups=groups, batches=_LazySplit(local, counts))
+
+
+class _LazySplit:
+    """``list(torch.split(local, counts))`` built on first use: the fused epoch never looks at it."""
+
+    def __init__(self, local, counts):
+        self._local, self._counts, self._parts = local, counts, None
+
+    def _get(self):
+        if self._parts is None:
+            self._parts = list(torch.split(self._local, self._counts))
+        return self._parts
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._counts)
+
+    def __getitem__(self, i):
+        return self._get()[i]
