@@ -186,11 +186,12 @@ def main():
             # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (4 taps + rhs) FMAs
             n_mfma, n_blend = (float(v) / len(k3s) for v in ops.SPARSE_COUNTERS.tolist())
             flops = n_mfma * 2048 + n_blend * 64 * 2 * 5 + T_loc * P * 82  # + warp geometry (82 flops/voxel)
-            roof = {"kernel": "warp_gram_sparse_kernel<7,4> (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",
+            kname = "warp_gram_lt_kernel" if ops.SPARSE_VARIANT == "table" else "warp_gram_sparse_kernel"
+            roof = {"kernel": kname + "<7,4> (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",
                     "bound": "mfma", "achieved": flops / k3_avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": tjson.get(key + "_sparse"),
                     "launch_ms": 1e3 * k3_avg, "launches": len(k3s), "flops_per_launch": flops,
-                    "count": "flops of the products evaluated (16-neuron blocks that are non-zero in a half pass of 32 "
+                    "count": "flops of the products evaluated (16-neuron blocks that are non-zero in a half pass = 8x4 "
                              "voxels; MFMA + gather + rhs, from in-kernel counters) + 82 flops/voxel of warp geometry; "
                              "products with an exact zero are skipped, so this kernel is bound by instruction issue of "
                              "the per-voxel bookkeeping, not by the matrix pipe",

@@ -281,9 +281,14 @@ def pack_footprints_sparse(A, order):
 SPARSE_COUNTERS = None
 
 
-def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame_ids=None, workspace=None):
+# which zero-skipping kernel warp_gram_rhs_sparse runs: 'table' (local block table, 4 waves per SIMD) or 'static'
+SPARSE_VARIANT = 'table'
+
+
+def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame_ids=None, workspace=None, variant=None):
     """K3s.  Returns G (B,K,K), r (B,K) in the original neuron order."""
     global SPARSE_COUNTERS
+    lt = (variant or SPARSE_VARIANT) == 'table'
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
     dev = Aps.device
@@ -295,7 +300,7 @@ def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame
     B = tt.numel() if tt is not None else (fid.numel() if fid is not None else frames.shape[0])
     if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
         raise ValueError("warp_gram_rhs_sparse: frames must be float32 CUDA with unit inner stride")
-    need = lib.dnmf_warp_gram_rhs_sparse_workspace(P, K, B)
+    need = (lib.dnmf_warp_gram_rhs_sparse_lt_workspace if lt else lib.dnmf_warp_gram_rhs_sparse_workspace)(P, K, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
@@ -306,7 +311,7 @@ def warp_gram_rhs_sparse(Aps, K, order, row_mask, sz, beta, times, frames, frame
             SPARSE_COUNTERS = torch.zeros(2, dtype=torch.int64, device=dev)
         counters = SPARSE_COUNTERS
     with _timed("warp_gram_rhs_sparse"):
-        rc = lib.dnmf_warp_gram_rhs_sparse(
+        rc = (lib.dnmf_warp_gram_rhs_sparse_lt if lt else lib.dnmf_warp_gram_rhs_sparse)(
             Aps.data_ptr(), Aps.shape[-1], K, od.data_ptr(), row_mask.data_ptr(), X, Y, Z, beta.data_ptr(),
             beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(),
             workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())

@@ -126,6 +126,15 @@ int dnmf_warp_gram_rhs_sparse(const float *Aps, int Ks, int K, const int *order,
                               void *workspace, size_t workspace_bytes, unsigned long long *counters,
                               dnmf_stream_t stream);
 
+/* The same with a local block table: a wave keeps accumulators only for the (at most four) blocks it is working
+ * with and adds finished tiles into its slab, so four waves fit on a SIMD.  Same arguments and results. */
+size_t dnmf_warp_gram_rhs_sparse_lt_workspace(long P, int K, int B);
+int dnmf_warp_gram_rhs_sparse_lt(const float *Aps, int Ks, int K, const int *order, const unsigned char *row_mask,
+                                 int X, int Y, int Z, const float *beta, int T, const int *times, int B,
+                                 const float *frames, long ldf, const int *frame_ids, float *G, float *r,
+                                 void *workspace, size_t workspace_bytes, unsigned long long *counters,
+                                 dnmf_stream_t stream);
+
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
  * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.

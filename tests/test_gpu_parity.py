@@ -424,11 +424,14 @@ def test_demo_loop_recovers_traces(M, capsys):
     assert 0.15 < float(line.split("median")[1]) < 0.35, line
 
 
+@pytest.mark.parametrize("variant", ["table", "static"])
 @pytest.mark.parametrize("sz,K,T,sigma", [([96, 80, 1], 40, 5, 1.0), ([64, 48, 2], 100, 3, 0.7), ([40, 36, 3], 20, 4, 3.0),
-                                          ([33, 47, 1], 7, 6, 0.8)])
-def test_sparse_gram_equals_dense(M, O, sz, K, T, sigma):
+                                          ([33, 47, 1], 7, 6, 0.8), ([32, 32, 1], 100, 3, 3.0), ([48, 40, 2], 80, 3, 1.6)])
+def test_sparse_gram_equals_dense(M, O, sz, K, T, sigma, variant):
     """K3s (products with an exact zero skipped) against K3 and against the float64 oracle: footprints narrow
-    enough to underflow to exact zeros (sigma <= 1), and a dense case where nothing can be skipped."""
+    enough to underflow to exact zeros (sigma <= 1), dense cases where nothing can be skipped (for the table variant
+    that is the path with more than four active blocks per half pass), and both kernels (local block table / all
+    tiles in registers)."""
     from dnmf_amd import ops
     rng = np.random.RandomState(K)
     pos = rng.rand(K, 3) * np.array(sz)
@@ -447,7 +450,7 @@ def test_sparse_gram_equals_dense(M, O, sz, K, T, sigma):
         assert sp["occupancy"] < 0.6 and float((fp.A == 0).float().mean()) > 0.5
     Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), list(range(T)), frames)
     Gs, rs, _ = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), list(range(T)),
-                                         frames)
+                                         frames, variant=variant)
     # same products, same fp32 arithmetic; only the grouping of the partial sums differs
     gs, rsc = float(Gd.abs().max()), float(rd.abs().max())
     assert float((Gs - Gd).abs().max()) < 2e-6 * gs and float((rs - rd).abs().max()) < 2e-6 * rsc
@@ -475,9 +478,11 @@ def test_sparse_gram_full_size(M):
     frames = torch.rand(T, 512 * 512, device="cuda")
     sp = fp.packed_sparse()
     Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames)
-    Gs, rs, _ = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None, frames)
-    assert float((Gs - Gd).abs().max()) < 2e-6 * float(Gd.abs().max())
-    assert float((rs - rd).abs().max()) < 2e-6 * float(rd.abs().max())
+    for variant in ("table", "static"):
+        Gs, rs, _ = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None, frames,
+                                             variant=variant)
+        assert float((Gs - Gd).abs().max()) < 2e-6 * float(Gd.abs().max())
+        assert float((rs - rd).abs().max()) < 2e-6 * float(rd.abs().max())
     assert 0.05 < sp["occupancy"] < 0.5
 
 

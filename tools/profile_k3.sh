@@ -5,7 +5,7 @@ out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="$*"
-run() { name=$1; shift; timeout -k 10 150 rocprofv3 --kernel-include-regex "warp_gram.*kernel" --output-format csv -d "$out/$name" "$@" -- python3 tools/run_k3.py $ARGS > "$out/$name.log" 2>&1; }
+run() { name=$1; shift; timeout -k 10 150 rocprofv3 --kernel-include-regex "warp_gram.*kernel|gram_.*finish" --output-format csv -d "$out/$name" "$@" -- python3 tools/run_k3.py $ARGS > "$out/$name.log" 2>&1; }
 run trace --kernel-trace --stats
 run sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
 run sq2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM
