@@ -17,7 +17,8 @@ def main():
     for f in sorted(glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv"))):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kern = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dnmf::", "")
+            agg[kern + ":" + r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out[k] = sum(v) / len(v)
     for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
