@@ -11,7 +11,7 @@
 // for the 8 k-steps of each half pass (one set per half), and issues the MFMAs of tile (bi,bj) only if both
 // blocks are in S; a half pass with S empty costs its share of the coordinate pass and nothing else.  Accumulators stay statically indexed: the skips are
 // scalar branches around fully unrolled code.  The right-hand side is accumulated on the vector ALU.
-#include "common.hpp"
+#include "../dnmf_amd/csrc/common.hpp"
 
 #include <type_traits>
 
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
     constexpr int NQ = NTAP / 4;
     constexpr int SLAB = NB * NB * 256 + 128;
     constexpr int EMPTY = 15;
-    constexpr int KP = 8;            // k-steps per part: block sets are formed per half pass (32 voxels)
+    constexpr int KP = 8;            // k-steps per part: block sets are formed per KP*4 voxels (half a pass)
     constexpr int NPART = KS_NKS / KP;
-    static_assert(NPART == 2, "the block sets are formed for lanes 0-31 / 32-63");
+    constexpr int PW = 64 / NPART;   // lanes (= voxel records) per part
     __shared__ u32x4 s_row[4][NQ][KS_SS];
     __shared__ f32x4 s_w[4][NQ][KS_SS];
     __shared__ float s_y[4][KS_SS];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
                         const f32x4 ww = s_w[wave][q][vi];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            v = fmaf(*reinterpret_cast<const float *>(Ab + (size_t)(rr[e] + boff)), ww[e], v);
+                            v = fmaf(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(&s_w[wave][0][0]) + ((rr[e] + boff) & 1020u)), ww[e], v);
                     }
                     frag[sl][ks] = v;
                     rsum = fmaf(v, s_y[wave][vi], rsum);
@@ -404,30 +404,21 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
             for (int c = 0; c < NTAP; ++c) rows[c] = 0u, voxs[c] = 0u, w[c] = 0.0f;
             if (x < vol.X && y < vol.Y && z < vol.Z) {
                 const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
-                // per axis: weight 0 for a corner outside the volume (its product with any other weight is then 0, the
-                // same value the per-corner test of the gather gives) and the corner index clamped into the volume
-                const float wxm[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
-                const float wym[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
-                const int xc[2] = {min(max(sm.x0, 0), vol.X - 1), min(max(sm.x0 + 1, 0), vol.X - 1)};
-                const int yc[2] = {min(max(sm.y0, 0), vol.Y - 1), min(max(sm.y0 + 1, 0), vol.Y - 1)};
-                float wzm[2] = {1.0f, 0.0f};
-                int zc[2] = {0, 0};
-                if (NTAP == 8) {
-                    wzm[0] = in_range(sm.z0, vol.Z) ? sm.wz0 : 0.0f, wzm[1] = in_range(sm.z0 + 1, vol.Z) ? sm.wz1 : 0.0f;
-                    zc[0] = min(max(sm.z0, 0), vol.Z - 1), zc[1] = min(max(sm.z0 + 1, 0), vol.Z - 1);
-                }
 #pragma unroll
                 for (int c = 0; c < NTAP; ++c) {
                     const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                    float wc = __fmul_rn(wxm[dx], wym[dy]);
-                    unsigned vox = (unsigned)(xc[dx] * vol.Y + yc[dy]);
+                    const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
+                    bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y);
+                    float wc = __fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0);
+                    unsigned vox = (unsigned)(cx * vol.Y + cy);
                     if (NTAP == 8) {
-                        wc = __fmul_rn(wc, wzm[dz]);
-                        vox = vox * (unsigned)vol.Z + (unsigned)zc[dz];
+                        ok = ok && in_range(cz, vol.Z);
+                        wc = __fmul_rn(wc, dz ? sm.wz1 : sm.wz0);
+                        vox = vox * (unsigned)vol.Z + (unsigned)cz;
                     }
-                    w[c] = wc;
-                    voxs[c] = vox;
-                    rows[c] = vox * row_bytes;
+                    w[c] = ok ? wc : 0.0f;
+                    voxs[c] = ok ? vox : 0u;
+                    rows[c] = voxs[c] * row_bytes;
                 }
                 yv = yb[((long)x * vol.Y + y) * vol.Z + z];
                 unsigned mk[NTAP];
@@ -443,17 +434,15 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
             }
             s_y[wave][lane] = yv;
         }
-        // wave-uniform block sets of the two half passes: OR of m over lanes 0-31 and 32-63 (rows of 16 lanes first
-        // with shifted DPP reads, then row 0 into row 1 and row 2 into row 3), read from lanes 31 and 63
-        unsigned Sw;
-        {
-            int v = (int)m;
-            v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
-            v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
-            v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
-            v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
-            v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1 and 3
-            Sw = (unsigned)__builtin_amdgcn_readlane(v, 31) | ((unsigned)__builtin_amdgcn_readlane(v, 63) << 8);
+        // wave-uniform block sets of the parts (lanes PW g .. PW g + PW-1 hold the voxels of part g's k-steps),
+        // packed 8 bits per part
+        unsigned Sw = 0;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const unsigned long long bal = __ballot((m >> bb) & 1u);
+#pragma unroll
+            for (int g = 0; g < NPART; ++g)
+                Sw |= (((bal >> (PW * g)) & ((1ull << PW) - 1ull)) != 0ull ? 1u : 0u) << (8 * g + bb);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -461,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
 
 #pragma unroll 1
         for (int h = 0; h < NPART; ++h) {
-            const unsigned S = (Sw >> (8 * h)) & 0xffu;
+            const unsigned S = (__builtin_amdgcn_readfirstlane(Sw) >> (8 * h)) & 0xffu;
             if (S == 0) continue;
             const int ks0 = h * KP;
             if (__builtin_popcount(S) <= NL) {
