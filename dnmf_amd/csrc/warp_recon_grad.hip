@@ -56,36 +56,41 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
         int x, yy, z;
         voxel_xyz(p, vol, x, yy, z);
         const Sample sm = make_sample_t<HASZ>(bt, vol, x, yy, z);
+        // Branch-free gather: corner indices clamped into the volume, per-axis weights (w) and validity flags (v)
+        // zeroed for corners outside it.  A corner's value weight is wx*wy*wz and its x-derivative weight
+        // +-vx*wy*wz (ATen's grid_sampler backward skips out-of-bounds corners), so everything factorises per axis.
+        const float wx[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
+        const float wy[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
+        const float vx[2] = {in_range(sm.x0, vol.X) ? 1.0f : 0.0f, in_range(sm.x0 + 1, vol.X) ? 1.0f : 0.0f};
+        const float vy[2] = {in_range(sm.y0, vol.Y) ? 1.0f : 0.0f, in_range(sm.y0 + 1, vol.Y) ? 1.0f : 0.0f};
+        const int xo[2] = {min(max(sm.x0, 0), vol.X - 1) * YZ, min(max(sm.x0 + 1, 0), vol.X - 1) * YZ};
+        const int yo[2] = {min(max(sm.y0, 0), vol.Y - 1) * vol.Z, min(max(sm.y0 + 1, 0), vol.Y - 1) * vol.Z};
         float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-            const int cz = sm.z0 + dz;
-            const float wz = dz ? sm.wz1 : sm.wz0;
-            const float sgz = dz ? 1.0f : -1.0f;
+            const int zo = HASZ ? min(max(sm.z0 + dz, 0), vol.Z - 1) : 0;
+            float sv[2][2];  // [dy][dx]
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int cy = sm.y0 + dy;
-                const float wy = dy ? sm.wy1 : sm.wy0;
-                const float sgy = dy ? 1.0f : -1.0f;
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int cx = sm.x0 + dx;
-                    const float wx = dx ? sm.wx1 : sm.wx0;
-                    const float sgx = dx ? 1.0f : -1.0f;
-                    if (in_range(cx, vol.X) && in_range(cy, vol.Y) && (!HASZ || in_range(cz, vol.Z))) {
-                        const float val = s[(long)cx * YZ + cy * vol.Z + (HASZ ? cz : 0)];
-                        if (HASZ) {
-                            rec = fmaf(val, wx * wy * wz, rec);
-                            g[0] = fmaf(val, sgx * wy * wz, g[0]);
-                            g[1] = fmaf(val, wx * sgy * wz, g[1]);
-                            g[2] = fmaf(val, wx * wy * sgz, g[2]);
-                        } else {
-                            rec = fmaf(val, wx * wy, rec);
-                            g[0] = fmaf(val, sgx * wy, g[0]);
-                            g[1] = fmaf(val, wx * sgy, g[1]);
-                        }
-                    }
-                }
+                for (int dx = 0; dx < 2; ++dx) sv[dy][dx] = s[xo[dx] + yo[dy] + zo];
+            const float a0 = fmaf(wx[1], sv[0][1], wx[0] * sv[0][0]);  // x-interpolated rows y0, y1
+            const float a1 = fmaf(wx[1], sv[1][1], wx[0] * sv[1][0]);
+            const float d0 = fmaf(vx[1], sv[0][1], -(vx[0] * sv[0][0]));  // x-differences of the rows
+            const float d1 = fmaf(vx[1], sv[1][1], -(vx[0] * sv[1][0]));
+            const float r2 = fmaf(wy[1], a1, wy[0] * a0);       // value of this z-slice
+            const float gx2 = fmaf(wy[1], d1, wy[0] * d0);
+            const float gy2 = fmaf(vy[1], a1, -(vy[0] * a0));
+            if (HASZ) {
+                const bool zin = in_range(sm.z0 + dz, vol.Z);
+                const float wz = zin ? (dz ? sm.wz1 : sm.wz0) : 0.0f;
+                const float vz = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
+                rec = fmaf(wz, r2, rec);
+                g[0] = fmaf(wz, gx2, g[0]);
+                g[1] = fmaf(wz, gy2, g[1]);
+                g[2] = fmaf(vz, r2, g[2]);
+            } else {
+                rec = r2, g[0] = gx2, g[1] = gy2;
             }
         }
         if (recon) recon[(long)b * vol.P + p] = rec;
