@@ -44,13 +44,20 @@ __global__ __launch_bounds__(256) void recon_image_kernel(const float *__restric
         }
     }
 
-    for (long g = g_begin; g < g_end; ++g) {
+    // footprint rows of the first group; inside the loop the next group's rows are requested before the MFMAs of the
+    // current one so that their latency hides behind 4*NB*NF matrix instructions
+    auto load_rows = [&](long g, f32x4 (&dst)[NB]) {
         const long p0 = g * 16;
         const long prow = p0 + vi < P ? p0 + vi : P - 1;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(Apk + prow * Kp + q * KQ);
-        f32x4 a4[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) a4[i] = src[i];
+        for (int i = 0; i < NB; ++i) dst[i] = src[i];
+    };
+    f32x4 a4[NB], a4n[NB];
+    load_rows(g_begin, a4);
+    for (long g = g_begin; g < g_end; ++g) {
+        const long p0 = g * 16;
+        load_rows(g + 1 < g_end ? g + 1 : g, a4n);
         f32x4 acc[NF];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -63,6 +70,8 @@ __global__ __launch_bounds__(256) void recon_image_kernel(const float *__restric
                     acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], bq[nf][4 * i + e], acc[nf], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a4[i] = a4n[i];
         // D[row = voxel 4q + r][col = frame vi]
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
