@@ -107,6 +107,35 @@ __device__ __forceinline__ Sample make_sample(const float *b, const Volume &vol,
 
 __device__ __forceinline__ bool in_range(int i, int n) { return (unsigned)i < (unsigned)n; }
 
+// The NTAP = 4 (Z == 1) or 8 gather taps of a sample, corner order of ATen's grid_sampler (dx fastest, then dy,
+// then dz): weight w[c] (0 for a corner outside the volume: per axis the weight of an outside corner is zeroed,
+// and a product with a zero factor is the zero the per-corner bounds test yields) and voxel index vox[c] (corner
+// clamped into the volume, so it can always be dereferenced).
+template <int NTAP>
+__device__ __forceinline__ void make_taps(const Sample &sm, const Volume &vol, float *w, unsigned *vox) {
+    const float wxm[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
+    const float wym[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
+    const int xc[2] = {min(max(sm.x0, 0), vol.X - 1), min(max(sm.x0 + 1, 0), vol.X - 1)};
+    const int yc[2] = {min(max(sm.y0, 0), vol.Y - 1), min(max(sm.y0 + 1, 0), vol.Y - 1)};
+    float wzm[2] = {1.0f, 0.0f};
+    int zc[2] = {0, 0};
+    if (NTAP == 8) {
+        wzm[0] = in_range(sm.z0, vol.Z) ? sm.wz0 : 0.0f, wzm[1] = in_range(sm.z0 + 1, vol.Z) ? sm.wz1 : 0.0f;
+        zc[0] = min(max(sm.z0, 0), vol.Z - 1), zc[1] = min(max(sm.z0 + 1, 0), vol.Z - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < NTAP; ++c) {
+        const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+        float wc = __fmul_rn(wxm[dx], wym[dy]);
+        unsigned v = (unsigned)(xc[dx] * vol.Y + yc[dy]);
+        if (NTAP == 8) {
+            wc = __fmul_rn(wc, wzm[dz]);
+            v = v * (unsigned)vol.Z + (unsigned)zc[dz];
+        }
+        w[c] = wc, vox[c] = v;
+    }
+}
+
 // Load the 30 coefficients of frame t from beta (10,3,T) into b[a*3+d].
 __device__ __forceinline__ void load_beta(const float *__restrict__ beta, int T, int t, float *b) {
 #pragma unroll

@@ -157,21 +157,10 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
         if (x < vol.X && y < vol.Y && z < vol.Z) {
             const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
+            unsigned voxs[NTAP];
+            make_taps<NTAP>(sm, vol, w, voxs);
 #pragma unroll
-            for (int c = 0; c < NTAP; ++c) {
-                const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
-                bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y);
-                float wc = __fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0);
-                unsigned vox = (unsigned)(cx * vol.Y + cy);
-                if (NTAP == 8) {  // Z == 1: the z weight is exactly 1 and the slice index 0
-                    ok = ok && in_range(cz, vol.Z);
-                    wc = __fmul_rn(wc, dz ? sm.wz1 : sm.wz0);
-                    vox = vox * (unsigned)vol.Z + (unsigned)cz;
-                }
-                w[c] = ok ? wc : 0.0f;
-                rows[c] = ok ? vox * row_bytes : 0u;
-            }
+            for (int c = 0; c < NTAP; ++c) rows[c] = voxs[c] * row_bytes;
             yv = yb[((long)x * vol.Y + y) * vol.Z + z];
         }
         const int buf = s & 1;

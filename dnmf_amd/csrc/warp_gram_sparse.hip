@@ -125,22 +125,9 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_sparse_kerne
             for (int c = 0; c < NTAP; ++c) rows[c] = 0u, voxs[c] = 0u, w[c] = 0.0f;
             if (x < vol.X && y < vol.Y && z < vol.Z) {
                 const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
+                make_taps<NTAP>(sm, vol, w, voxs);
 #pragma unroll
-                for (int c = 0; c < NTAP; ++c) {
-                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                    const int cx = sm.x0 + dx, cy = sm.y0 + dy, cz = sm.z0 + dz;
-                    bool ok = in_range(cx, vol.X) && in_range(cy, vol.Y);
-                    float wc = __fmul_rn(dx ? sm.wx1 : sm.wx0, dy ? sm.wy1 : sm.wy0);
-                    unsigned vox = (unsigned)(cx * vol.Y + cy);
-                    if (NTAP == 8) {
-                        ok = ok && in_range(cz, vol.Z);
-                        wc = __fmul_rn(wc, dz ? sm.wz1 : sm.wz0);
-                        vox = vox * (unsigned)vol.Z + (unsigned)cz;
-                    }
-                    w[c] = ok ? wc : 0.0f;
-                    voxs[c] = ok ? vox : 0u;
-                    rows[c] = voxs[c] * row_bytes;
-                }
+                for (int c = 0; c < NTAP; ++c) rows[c] = voxs[c] * row_bytes;
                 yv = yb[((long)x * vol.Y + y) * vol.Z + z];
                 // all mask bytes requested together (one round trip); a tap without weight contributes no block
                 unsigned mk[NTAP];
@@ -404,31 +391,9 @@ __global__ __launch_bounds__(256, 3) void warp_gram_lt_kernel(SparseParams p) {
             for (int c = 0; c < NTAP; ++c) rows[c] = 0u, voxs[c] = 0u, w[c] = 0.0f;
             if (x < vol.X && y < vol.Y && z < vol.Z) {
                 const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
-                // per axis: weight 0 for a corner outside the volume (its product with any other weight is then 0, the
-                // same value the per-corner test of the gather gives) and the corner index clamped into the volume
-                const float wxm[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
-                const float wym[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
-                const int xc[2] = {min(max(sm.x0, 0), vol.X - 1), min(max(sm.x0 + 1, 0), vol.X - 1)};
-                const int yc[2] = {min(max(sm.y0, 0), vol.Y - 1), min(max(sm.y0 + 1, 0), vol.Y - 1)};
-                float wzm[2] = {1.0f, 0.0f};
-                int zc[2] = {0, 0};
-                if (NTAP == 8) {
-                    wzm[0] = in_range(sm.z0, vol.Z) ? sm.wz0 : 0.0f, wzm[1] = in_range(sm.z0 + 1, vol.Z) ? sm.wz1 : 0.0f;
-                    zc[0] = min(max(sm.z0, 0), vol.Z - 1), zc[1] = min(max(sm.z0 + 1, 0), vol.Z - 1);
-                }
+                make_taps<NTAP>(sm, vol, w, voxs);
 #pragma unroll
-                for (int c = 0; c < NTAP; ++c) {
-                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                    float wc = __fmul_rn(wxm[dx], wym[dy]);
-                    unsigned vox = (unsigned)(xc[dx] * vol.Y + yc[dy]);
-                    if (NTAP == 8) {
-                        wc = __fmul_rn(wc, wzm[dz]);
-                        vox = vox * (unsigned)vol.Z + (unsigned)zc[dz];
-                    }
-                    w[c] = wc;
-                    voxs[c] = vox;
-                    rows[c] = vox * row_bytes;
-                }
+                for (int c = 0; c < NTAP; ++c) rows[c] = voxs[c] * row_bytes;
                 yv = yb[((long)x * vol.Y + y) * vol.Z + z];
                 unsigned mk[NTAP];
 #pragma unroll
