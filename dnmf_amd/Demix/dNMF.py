@@ -232,6 +232,9 @@ class DeformableNMF:
         # skipped; same sums), 'auto' = K3s when on average fewer than half of the 16-neuron blocks of a
         # footprint row are non-zero
         self.gram_kernel = 'auto'
+        # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
+        # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
+        self.group = None
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
     @staticmethod
@@ -270,6 +273,25 @@ class DeformableNMF:
         ops.mu_spatial(A_dev, A1.contiguous(), Cs, D_dev, gamma)
         return A_dev.double().cpu().numpy().reshape(A.shape)
 
+    def spatial_step(self, registered, D=None, gamma=None, frame_ids=None):
+        """One multiplicative update of ``fp.A`` from the registered frames this process holds (the update the
+        reference leaves commented out at :174, on the flattened voxel axis): K5 on the local frames, ONE all-reduce
+        (sum) of ``A1`` (P,K) and ``C_s`` (K,K) over ``self.group`` when the T axis is sharded, then K6 -- every rank
+        ends with the same footprints.  ``registered`` (T_local,P) fp32 CUDA rows, ``D`` None or (X,Y,Z,K)."""
+        fp = self.fp
+        if fp.K > 128:
+            raise NotImplementedError("spatial_step: K > 128")
+        C = self.C.to(device, torch.float32).contiguous()
+        A1, Cs = ops.spatial_accum(registered, C, frame_ids=frame_ids, times=frame_ids)
+        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
+            torch.distributed.all_reduce(A1, group=self.group)
+            torch.distributed.all_reduce(Cs, group=self.group)
+        A2 = fp.A.reshape(fp.P, fp.K).contiguous()
+        Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(fp.P, fp.K).contiguous()
+        ops.mu_spatial(A2, A1, Cs, Dd, gamma)
+        fp.A = A2.view(*fp.sz_list, fp.K)
+        return fp.A
+
     # ---- fit steps -------------------------------------------------------------------------------------
     def _gather_frames(self, loader):
         """All frames the loader yields, in its order, resident on the GPU as (T,P) plus their indices."""
@@ -295,7 +317,7 @@ class DeformableNMF:
             T_loc = frames.shape[0]
             G, r = self._gram_rhs(frames, order)
             Csel = self.C.to(device, torch.float32)[:, order.long()].contiguous()
-            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c)
+            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c, group=self.group)
             C = self.C.to(device, torch.float32).clone()
             C[:, order.long()] = Cnew
             self.C = C
@@ -472,19 +494,31 @@ class DeformableNMF:
         return out
 
 
-def _mu_temporal(G, r, C, gamma, iters):
+def _mu_temporal(G, r, C, gamma, iters, group=None):
     """``iters`` multiplicative updates on (T,K,K) / (T,K) Gram data.
 
     ``C`` fp32 (K,T): the state update_footprints starts from (the reference's ``self.C``); without the
     neighbour term the whole loop is one K4 launch (fp64 inside, one rounding to fp32 at the end, as
     reference :177).  ``C`` fp64, or gamma != 0: the fp64 state is iterated with the one-round kernel.
-    Returns a tensor of C's dtype."""
+    ``group``: torch.distributed group when the frames are a contiguous T-shard of rank order: with gamma != 0
+    every round first exchanges the boundary columns (one all-gather of 2K doubles) so that the first / last frame
+    of a shard sees its true neighbour instead of the replicated edge.  Returns a tensor of C's dtype."""
     if C.dtype == torch.float32 and (gamma is None or gamma == 0):
         return ops.mu_temporal(G, r, C.contiguous().clone(), iters)
     a = C.double().contiguous().clone()
     b = torch.empty_like(a)
+    sharded = group is not None and gamma is not None and gamma != 0 and torch.distributed.get_world_size(group) > 1
+    if sharded:
+        rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+        edges = [torch.empty((2, a.shape[0]), dtype=torch.float64, device=a.device) for _ in range(world)]
     for _ in range(iters):
-        ops.mu_temporal_step(G, r, a, b, 0.0 if gamma is None else float(gamma))
+        left = right = None
+        if sharded:
+            mine = torch.stack((a[:, 0], a[:, -1])).contiguous()
+            torch.distributed.all_gather(edges, mine, group=group)
+            left = edges[rank - 1][1].contiguous() if rank > 0 else None
+            right = edges[rank + 1][0].contiguous() if rank + 1 < world else None
+        ops.mu_temporal_step(G, r, a, b, 0.0 if gamma is None else float(gamma), left, right)
         a, b = b, a
     return a.to(C.dtype)
 

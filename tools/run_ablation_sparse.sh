@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing-only: the table Gram kernel with its gathers served from LDS instead of global memory (results are wrong)
-cd $GRAFT_REPO_ROOT
+cd $GRAFT_REPO_ROOT && python tools/make_ablation.py
 cp dnmf_amd/libdnmf_hip.so /tmp/lib_keep.so
 python tools/run_k3.py --frames 4000 --reps 3 --sparse | tail -1
 SRC=$(python - <<'PY'
