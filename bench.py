@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iter-c", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--gram", choices=["auto", "dense", "sparse"], default="auto",
                     help="Gram kernel: K3 (dense), K3s (exact-zero blocks skipped) or by footprint occupancy")
     return ap.parse_args()
@@ -88,11 +90,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     group = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
         group = dist.group.WORLD
 
     from dnmf_amd import ops
