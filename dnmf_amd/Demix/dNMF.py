@@ -111,6 +111,8 @@ class ExponentialFP(nn.Module):
         self._packed_version = None
         self._sparse = None
         self._sparse_version = None
+        self._sparse_pairs = None
+        self._sparse_pairs_version = None
 
     @staticmethod
     def quadratic_basis(P):
@@ -146,6 +148,25 @@ class ExponentialFP(nn.Module):
                 out[:part.shape[0]] += part
         return out
 
+    def _zorder(self):
+        """Neuron indices sorted along a Z-order curve of the footprint centroids (x,y), int32 on the GPU."""
+        A2 = self.A.reshape(self.P, self.K)
+        mass = A2.sum(0).clamp_min(1e-30)
+        cen = (self.flow_id.reshape(self.P, 3).T @ A2) / mass            # (3,K) centroids
+        q = (cen[:2] / torch.tensor(self.sz_list[:2], device=cen.device)[:, None]).clamp(0, 1 - 1e-6)
+        q = (q * 1024).long().cpu().numpy()
+        code = np.zeros(self.K, dtype=np.int64)
+        for bit in range(10):                                           # interleave the bits of x and y
+            code |= ((q[0] >> bit) & 1) << (2 * bit + 1) | ((q[1] >> bit) & 1) << (2 * bit)
+        return torch.from_numpy(np.argsort(code, kind="stable").astype(np.int32)).to(device)
+
+    @staticmethod
+    def _sparse_layout(A2, order):
+        Aps, mask = ops.pack_footprints_sparse(A2, order)
+        nb = Aps.shape[1] // 16
+        bits = (mask[:, None] >> torch.arange(nb, device=mask.device, dtype=torch.uint8)[None, :]) & 1
+        return {"Aps": Aps, "order": order, "row_mask": mask, "occupancy": float(bits.float().mean())}
+
     def packed_sparse(self):
         """Layout for the zero-skipping Gram kernel K3s: neurons ordered along a Z-order curve of their footprint
         centroids, ``Aps`` (P,Ks) in that order, one block-occupancy byte per footprint row, and the mean
@@ -154,21 +175,28 @@ class ExponentialFP(nn.Module):
             return None
         key = (self.A.data_ptr(), self.A._version)
         if self._sparse is None or self._sparse_version != key:
-            A2 = self.A.reshape(self.P, self.K)
-            mass = A2.sum(0).clamp_min(1e-30)
-            cen = (self.flow_id.reshape(self.P, 3).T @ A2) / mass            # (3,K) centroids
-            q = (cen[:2] / torch.tensor(self.sz_list[:2], device=cen.device)[:, None]).clamp(0, 1 - 1e-6)
-            q = (q * 1024).long().cpu().numpy()
-            code = np.zeros(self.K, dtype=np.int64)
-            for bit in range(10):                                           # interleave the bits of x and y
-                code |= ((q[0] >> bit) & 1) << (2 * bit + 1) | ((q[1] >> bit) & 1) << (2 * bit)
-            order = torch.from_numpy(np.argsort(code, kind="stable").astype(np.int32)).to(device)
-            Aps, mask = ops.pack_footprints_sparse(self.A.contiguous(), order)
-            nb = Aps.shape[1] // 16
-            bits = (mask[:, None] >> torch.arange(nb, device=mask.device, dtype=torch.uint8)[None, :]) & 1
-            self._sparse = {"Aps": Aps, "order": order, "row_mask": mask, "occupancy": float(bits.float().mean())}
+            self._sparse = self._sparse_layout(self.A.contiguous(), self._zorder())
             self._sparse_version = key
         return self._sparse
+
+    def packed_sparse_pairs(self, group=64):
+        """K > 128: the neurons, in Z-order, are cut into groups of ``group`` and every pair of groups gets its own
+        K3s layout (a mask byte holds 8 blocks of 16).  Returns ``[(cols (n,) long, layout), ...]``; ``cols`` are
+        the original neuron indices of the pair, in the column order of ``layout["Aps"]`` before its own sort."""
+        key = (self.A.data_ptr(), self.A._version, group)
+        if self._sparse_pairs is None or self._sparse_pairs_version != key:
+            z = self._zorder().long()
+            groups = [z[s0:s0 + group] for s0 in range(0, self.K, group)]
+            A2 = self.A.reshape(self.P, self.K)
+            pairs = []
+            for i in range(len(groups)):
+                for j in range(i + 1, len(groups)):
+                    cols = torch.cat([groups[i], groups[j]])
+                    sub = A2[:, cols].contiguous()
+                    ident = torch.arange(cols.numel(), dtype=torch.int32, device=device)  # already Z-ordered
+                    pairs.append((cols, self._sparse_layout(sub, ident)))
+            self._sparse_pairs, self._sparse_pairs_version = pairs, key
+        return self._sparse_pairs
 
     def forward(self, times, C):
         """Returns ``(A_tC (B,X,Y,Z), A_t (B,K,X,Y,Z), grid (X,Y,Z,3,B), reg (B))`` for the frames ``times``."""
@@ -235,6 +263,7 @@ class DeformableNMF:
         # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
         # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
         self.group = None
+        self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
     @staticmethod
@@ -284,8 +313,15 @@ class DeformableNMF:
         C = self.C.to(device, torch.float32).contiguous()
         A1, Cs = ops.spatial_accum(registered, C, frame_ids=frame_ids, times=frame_ids)
         if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
-            torch.distributed.all_reduce(A1, group=self.group)
-            torch.distributed.all_reduce(Cs, group=self.group)
+            if torch.distributed.get_backend(self.group) == "nccl":
+                # one process per GPU: the library's own RCCL communicator (C1), built on first use
+                if self._comm is None:
+                    self._comm = ops.Communicator(self.group)
+                self._comm.all_reduce_(A1)
+                self._comm.all_reduce_(Cs)
+            else:  # ranks that share a card or run without one (gloo rehearsal): RCCL cannot span them
+                torch.distributed.all_reduce(A1, group=self.group)
+                torch.distributed.all_reduce(Cs, group=self.group)
         A2 = fp.A.reshape(fp.P, fp.K).contiguous()
         Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(fp.P, fp.K).contiguous()
         ops.mu_spatial(A2, A1, Cs, Dd, gamma)
@@ -340,10 +376,22 @@ class DeformableNMF:
             return A_t, Yi, Yv
 
     def _gram_rhs(self, frames, order):
-        """Per-frame Gram matrices and right-hand sides under the current warp (K3 or K3s)."""
-        fp = self.fp
+        """Per-frame Gram matrices and right-hand sides under the current warp, summed over the channels."""
+        G = r = None
+        for fp, cols in self._channels():
+            Gc, rc = self._gram_rhs_one(fp, frames if cols is None else frames[:, cols], order)
+            G, r = (Gc, rc) if G is None else (G.add_(Gc), r.add_(rc))
+        return G, r
+
+    def _channels(self):
+        """``[(spatial model, slice of a frame row)]``: one entry, the whole row, for the reference's single-channel
+        model; MultiChannelDNMF lists its colour channels here."""
+        return [(self.fp, None)]
+
+    def _gram_rhs_one(self, fp, frames, order):
+        """K3 or K3s on the footprints of ``fp``."""
         if fp.K > 127:
-            return self._gram_rhs_grouped(frames, order)
+            return self._gram_rhs_grouped(fp, frames, order)
         sp = fp.packed_sparse() if self.gram_kernel in ('auto', 'sparse') else None
         if sp is not None and (self.gram_kernel == 'sparse' or sp["occupancy"] < 0.5):
             G, r, self._ws_k3 = ops.warp_gram_rhs_sparse(sp["Aps"], fp.K, sp["order"], sp["row_mask"], fp.sz_list,
@@ -353,15 +401,26 @@ class DeformableNMF:
                                                   frames, workspace=self._ws_k3)
         return G, r
 
-    def _gram_rhs_grouped(self, frames, order, group=56):
-        """K > 127: the Gram kernel holds at most 112 channels, so neurons are cut into groups of 56 and every PAIR
-        of groups is one K3 launch on their union; the launch yields both diagonal blocks and the off-diagonal
-        block of the pair (diagonal blocks are recomputed by every pair they belong to)."""
-        fp = self.fp
+    def _gram_rhs_grouped(self, fp, frames, order):
+        """K > 127: one launch holds at most 8 blocks of 16 channels, so the neurons are cut into groups and every
+        PAIR of groups is one launch on their union; the launch yields both diagonal blocks and the off-diagonal
+        block of the pair (diagonal blocks are recomputed by every pair they belong to).  K3s (groups of 64 along
+        the Z-order curve) unless ``gram_kernel == 'dense'`` or the footprints are dense (K3, groups of 56)."""
         K, B = fp.K, order.numel()
-        groups = [list(range(s0, min(K, s0 + group))) for s0 in range(0, K, group)]
         G = torch.empty((B, K, K), dtype=torch.float32, device=device)
         r = torch.empty((B, K), dtype=torch.float32, device=device)
+        if self.gram_kernel in ('auto', 'sparse'):
+            pairs = fp.packed_sparse_pairs()
+            if self.gram_kernel == 'sparse' or max(sp["occupancy"] for _, sp in pairs) < 0.5:
+                for cols, sp in pairs:
+                    Gp, rp, self._ws_k3 = ops.warp_gram_rhs_sparse(sp["Aps"], cols.numel(), sp["order"], sp["row_mask"],
+                                                                   fp.sz_list, fp.beta.detach(), order, frames,
+                                                                   workspace=self._ws_k3)
+                    G[:, cols[:, None], cols[None, :]] = Gp
+                    r[:, cols] = rp
+                return G, r
+        group = 56
+        groups = [list(range(s0, min(K, s0 + group))) for s0 in range(0, K, group)]
         for i in range(len(groups)):
             for j in range(i + 1, len(groups)):
                 cols = groups[i] + groups[j]
@@ -372,18 +431,48 @@ class DeformableNMF:
                 r[:, idx] = rp
         return G, r
 
-    def _recon_cache(self, frame_ids=None):
-        """Reconstruction images S_t = A.C_t of all T frames (C is constant inside update_motion)."""
-        fp = self.fp
-        lds = (fp.P + 3) // 4 * 4
-        if 4 * lds * fp.T > RECON_CACHE_LIMIT:
+    def _recon_cache(self):
+        """Reconstruction images S_t = A.C_t of all T frames, one (T,lds) tensor per channel (C is constant inside
+        update_motion); None when they do not fit ``RECON_CACHE_LIMIT``."""
+        chans = self._channels()
+        fp0 = chans[0][0]
+        lds = (fp0.P + 3) // 4 * 4
+        if 4 * lds * fp0.T * len(chans) > RECON_CACHE_LIMIT:
             return None
-        S = torch.empty((fp.T, lds), dtype=torch.float32, device=device)
         C = self.C.to(device, torch.float32).contiguous()
-        all_t = torch.arange(fp.T, dtype=torch.int32, device=device)
-        for s in range(0, fp.T, 32768):
-            fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768])
-        return S
+        all_t = torch.arange(fp0.T, dtype=torch.int32, device=device)
+        out = []
+        for fp, _ in chans:
+            S = torch.empty((fp.T, lds), dtype=torch.float32, device=device)
+            for s in range(0, fp.T, 32768):
+                fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768])
+            out.append(S)
+        return out
+
+    def _k2(self, S_all, Cdev, frames, frame_ids, times, grad, norm, want):
+        """K2 for one set of frames on every channel: ``grad`` (10,3,T) is incremented by d mse / d beta, the mean
+        running over ``norm`` frames (0 = all of ``times``) x channels x voxels.  Returns the outputs of
+        ``ops.warp_recon_grad`` with the losses summed over channels."""
+        chans = self._channels()
+        nc = len(chans)
+        if nc > 1 and norm == 0:
+            norm = times.numel()
+        total = None
+        for c, (fp, cols) in enumerate(chans):
+            if S_all is not None:
+                S, s_ids = S_all[c], times
+            else:
+                S, s_ids = fp.recon_image(Cdev, times), None
+            out = ops.warp_recon_grad(S, s_ids, frames if cols is None else frames[:, cols], frame_ids, fp.sz_list,
+                                      fp.beta.detach(), times, grad=grad, want_loss=want, want_reg=want,
+                                      workspace=self._ws_k2, norm_frames=norm * nc)
+            self._ws_k2 = out["workspace"]
+            if total is None:
+                total = out
+            elif want:
+                total["loss"] += out["loss"]
+                total["frame_loss"] += out["frame_loss"]
+        return total
 
     def update_motion(self, dataloader, optimizer, gamma=0, epochs=20):
         """Reference :181-194: mini-batch steps of the caller's optimiser on ``fp.beta`` against
@@ -408,15 +497,8 @@ class DeformableNMF:
                 if times.numel() == 0:      # sharded: this global mini-batch has no frame here; still a step
                     optimizer.step()
                     continue
-                if S_all is not None:
-                    S, s_ids = S_all, times
-                else:
-                    S, s_ids = fp.recon_image(Cdev, times), None
                 want = self.verbose and batch_idx % 10 == 0
-                out = ops.warp_recon_grad(S, s_ids, frames, frame_ids, fp.sz_list, beta.detach(), times,
-                                          grad=beta.grad, want_loss=want, want_reg=want, workspace=self._ws_k2,
-                                          norm_frames=norm)
-                self._ws_k2 = out["workspace"]
+                out = self._k2(S_all, Cdev, frames, frame_ids, times, beta.grad, norm, want)
                 optimizer.step()
                 if want:
                     print('Recon: ' + str(out["loss"][0]))
@@ -471,10 +553,7 @@ class DeformableNMF:
                 if idx.numel() == 0:
                     continue
                 idx = idx.to(device, torch.int32)
-                out = ops.warp_recon_grad(S_all, idx, loader.frames_2d(), idx, fp.sz_list, beta, idx, grad=grad,
-                                          want_loss=self.verbose, want_reg=self.verbose, workspace=self._ws_k2,
-                                          norm_frames=nf)
-                self._ws_k2 = out["workspace"]
+                out = self._k2(S_all, None, loader.frames_2d(), idx, idx, grad, nf, self.verbose)
                 outs.append((idx, nf, out))
             ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1)
         state['step'] += n
@@ -492,6 +571,50 @@ class DeformableNMF:
             self.update_motion(dataloader, optimizer, gamma=gamma, epochs=epochs)
             out = self.update_footprints(testloader, batch_size, self.fp.sz_list, gamma_c=gamma_c, iter_c=iter_c)
         return out
+
+
+class MultiChannelDNMF(DeformableNMF):
+    """Several colour channels of one volume (BASELINE config 5, "C=3").  NOT in the reference, which has no channel
+    axis on this path: the channels are treated as extra voxels that share the warp ``beta`` and the
+    traces ``C`` -- channel ``c`` shows neuron ``k`` with footprint ``colours[c,k] * A[...,k]`` -- so every update
+    formula of the reference holds with the sums over voxels also running over channels:
+    ``G_t = sum_c A_t(c)^T A_t(c)``, ``r_t = sum_c A_t(c)^T y_t(c)``, loss = mean over batch x channels x voxels.
+
+    A frame is the concatenation of its channels, ``(C, X, Y, Z)``: loaders yield ``(B, C, X, Y, Z)`` and a
+    ``ResidentLoader`` is built on rows of ``C*P`` floats.  ``fp`` holds the uncoloured footprints and ``beta``."""
+
+    def __init__(self, sz, K, T, colours, positions=None):
+        super().__init__(sz, K, T, positions)
+        colours = torch.as_tensor(colours, dtype=torch.float32).to(device)
+        if colours.dim() != 2 or colours.shape[1] != K:
+            raise ValueError(f"colours must be (channels, K={K}), got {tuple(colours.shape)}")
+        self.colours = colours
+        self._chan_fp = None
+        self._chan_key = None
+
+    def _channels(self):
+        import copy
+        key = (self.fp.A.data_ptr(), self.fp.A._version, self.colours.data_ptr(), self.colours._version)
+        if self._chan_fp is None or self._chan_key != key:
+            P = self.fp.P
+            self._chan_fp = []
+            for c in range(self.colours.shape[0]):
+                f = copy.copy(self.fp)  # shares beta (the caller's optimiser steps one tensor) and the lattice
+                f.A = self.fp.A * self.colours[c]
+                f._packed = f._sparse = f._sparse_pairs = None
+                self._chan_fp.append((f, slice(c * P, (c + 1) * P)))
+            self._chan_key = key
+        return self._chan_fp
+
+    def update_footprints(self, testloader, batch_size, sz, gamma_c=1e-2, gamma_a=1e0, iter_c=10, return_dense=False):
+        """As DeformableNMF.update_footprints on the channel sums; the dense ``A_t`` return is not offered."""
+        if return_dense:
+            raise NotImplementedError("MultiChannelDNMF.update_footprints: return_dense")
+        return super().update_footprints(testloader, batch_size, sz, gamma_c=gamma_c, gamma_a=gamma_a, iter_c=iter_c,
+                                         return_dense=False)
+
+    def spatial_step(self, *a, **k):
+        raise NotImplementedError("MultiChannelDNMF.spatial_step")
 
 
 def _mu_temporal(G, r, C, gamma, iters, group=None):

@@ -42,6 +42,10 @@ SIGNATURES = {
     "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp]),
     "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _i, _d, _d, _d, _d, _i, _vp]),
     "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
+    "dnmf_comm_unique_id": (_i, [_vp]),
+    "dnmf_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "dnmf_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "dnmf_comm_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdnmf_hip.so")
 SOURCES = ["api_common.hip", "warp_gather.hip", "recon_image.hip", "warp_recon_grad.hip", "warp_gram_rhs.hip", "warp_gram_sparse.hip",
-           "mu_temporal.hip", "render_frames.hip", "adam_epoch.hip", "spatial_update.hip", "image_iwarp.hip"]
+           "mu_temporal.hip", "render_frames.hip", "adam_epoch.hip", "spatial_update.hip", "image_iwarp.hip", "collective.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 
@@ -34,7 +34,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB, "-ldl"]
     if verbose:
         print("[dnmf_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

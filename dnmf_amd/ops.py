@@ -245,6 +245,46 @@ def mu_spatial(A, A1, Cs, D=None, gamma=0.0):
     return A
 
 
+class Communicator:
+    """C1: the library's RCCL communicator over the ranks of a ``torch.distributed`` group (one process per GPU).
+
+    ``torch.distributed`` is only the out-of-band channel for the 128-byte id; the all-reduce itself is
+    ``dnmf_allreduce_sum_f32`` on torch's current stream.  ``group=None`` with no initialised default group gives a
+    one-rank communicator."""
+
+    def __init__(self, group=None):
+        import ctypes
+        import torch.distributed as dist
+        lib = _lib.load()
+        multi = dist.is_available() and dist.is_initialized()
+        self.nranks = dist.get_world_size(group) if multi else 1
+        self.rank = dist.get_rank(group) if multi else 0
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.dnmf_comm_unique_id(ident), "dnmf_comm_unique_id")
+        if self.nranks > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
+            t = t.cuda() if on_gpu else t
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = ctypes.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.dnmf_comm_init(ctypes.byref(handle), ident, self.nranks, self.rank), "dnmf_comm_init")
+        self._handle = handle
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over ranks of a contiguous fp32 CUDA tensor."""
+        t = _f32(t, "all_reduce_")
+        _lib.check(_lib.load().dnmf_allreduce_sum_f32(self._handle, _ptr(t), t.numel(), _stream()),
+                   "dnmf_allreduce_sum_f32")
+        return t
+
+    def close(self):
+        if self._handle:
+            _lib.check(_lib.load().dnmf_comm_destroy(self._handle), "dnmf_comm_destroy")
+            self._handle = None
+
+
 def image_iwarp(frames, frame_ids, sz, beta, times):
     """K7.  Registered frames (B,P): nearest-neighbour inverse warp under beta[:, :, times]."""
     X, Y, Z = (int(s) for s in sz)

@@ -165,6 +165,25 @@ int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const flo
 int dnmf_mu_spatial(float *A, const float *A1, const float *Cs, const float *D, double gamma, long P, int K,
                     dnmf_stream_t stream);
 
+/* ---- C1: frame-summed accumulators across the GPUs of a node -----------------------------------------
+ * With the T axis sharded over ranks the two sums over frames of update_spatial (A1 = Y_i C^T, dNMF.py:154, and
+ * Cs = C C^T, dNMF.py:153) are completed by ONE RCCL all-reduce each per update; nothing else on the path
+ * communicates.  The communicator is the only state the library ever holds, behind an opaque handle the caller owns.
+ * RCCL is bound at run time (dlopen of the librccl already in the process -- torch's -- else the system one), so
+ * the library loads on hosts without it and these calls then return DNMF_E_UNSUPPORTED.
+ *   dnmf_comm_unique_id: rank 0 fills `id` (HOST, DNMF_COMM_ID_BYTES) and hands it to the other ranks out of band
+ *     (the host mirror broadcasts it over the caller's torch.distributed group);
+ *   dnmf_comm_init: collective over the nranks processes, each with its own current HIP device;
+ *   dnmf_allreduce_sum_f32: buf (count floats, device) <- sum over ranks, in place, enqueued on `stream`;
+ *   dnmf_comm_destroy: releases the communicator (NULL is accepted).
+ * Positive return values of these four are ncclResult_t codes (text in dnmf_last_error). */
+#define DNMF_COMM_ID_BYTES 128
+typedef void *dnmf_comm_t;
+int dnmf_comm_unique_id(void *id_host);
+int dnmf_comm_init(dnmf_comm_t *comm, const void *id_host, int nranks, int rank);
+int dnmf_allreduce_sum_f32(dnmf_comm_t comm, float *buf, size_t count, dnmf_stream_t stream);
+int dnmf_comm_destroy(dnmf_comm_t comm);
+
 /* ---- K7: registered video ---------------------------------------------------------------------------
  * ExponentialFP.image_iwarp over the frames of spatial_pushforward (Demix/dNMF.py:81-83, 89-91, 95-103): every
  * lattice point takes the value of the voxel whose warped position ((n+1)/2 * sz, the reference's scaling

@@ -54,6 +54,13 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     rc = lib.dnmf_warp_gram_rhs(addr, 16, 3, 0, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr, 8, None)
     assert rc in (-2, -4)  # alignment or workspace, never a launch
     assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 3 * 28 * 256 * 4
+    # C1: arguments are checked before RCCL is looked up
+    assert lib.dnmf_comm_unique_id(None) == -1
+    assert lib.dnmf_comm_init(None, addr, 2, 0) == -1
+    handle = ctypes.c_void_p()
+    assert lib.dnmf_comm_init(ctypes.byref(handle), addr, 2, 2) == -2 and b"rank 2 of 2" in lib.dnmf_last_error()
+    assert lib.dnmf_allreduce_sum_f32(None, addr, 4, None) == -1
+    assert lib.dnmf_comm_destroy(None) == 0
 
 
 def test_product_has_no_cpu_fallback():

@@ -122,6 +122,28 @@ def test_G5_update_spatial(M):
                                rtol=2e-5)
 
 
+@pytest.mark.timeout(300)
+def test_rccl_communicator_single_rank(M):
+    """C1 through the C ABI on the one GPU of this box: a one-rank RCCL communicator whose all-reduce leaves the
+    buffer as it was, on torch's stream, between two kernels of the path.  (More than one rank needs one GPU per
+    rank; the two-rank exchange is covered with gloo in test_gpu_multiprocess.py.)"""
+    from dnmf_amd import ops
+    comm = ops.Communicator(None)
+    assert (comm.nranks, comm.rank) == (1, 0)
+    torch.manual_seed(0)
+    Y, C = torch.rand(16, 1000, device="cuda"), torch.rand(20, 16, device="cuda")
+    A1, Cs = ops.spatial_accum(Y, C)
+    ref1, ref2 = A1.clone(), Cs.clone()
+    comm.all_reduce_(A1)
+    comm.all_reduce_(Cs)
+    torch.cuda.synchronize()
+    assert torch.equal(A1, ref1) and torch.equal(Cs, ref2)
+    with pytest.raises(ValueError):
+        comm.all_reduce_(A1.double())
+    comm.close()
+    comm.close()  # idempotent
+
+
 def test_spatial_accum_chunks_and_shards(M):
     """A1 / C_s accumulated over two frame chunks (what two T-shards all-reduce) equal the one-shot result, and
     both equal float64 matmuls; K up to 128 and a ragged voxel count."""
@@ -486,9 +508,10 @@ def test_sparse_gram_full_size(M):
     assert 0.05 < sp["occupancy"] < 0.5
 
 
-@pytest.mark.parametrize("K", [130, 200])
-def test_more_than_127_neurons(M, O, K):
-    """BASELINE config 5's K=200: Gram by pairs of neuron groups, recon image by groups, through the fit steps."""
+@pytest.mark.parametrize("K,gram", [(130, "dense"), (200, "dense"), (200, "sparse"), (129, "sparse")])
+def test_more_than_127_neurons(M, O, K, gram):
+    """BASELINE config 5's K=200: Gram by pairs of neuron groups (K3 on groups of 56, K3s on groups of 64 along the
+    Z-order curve), recon image by groups, through the fit steps."""
     rng = np.random.RandomState(K)
     sz, T, bs = [28, 24, 2], 6, 3
     pos = rng.rand(K, 3) * np.array(sz)
@@ -506,6 +529,7 @@ def test_more_than_127_neurons(M, O, K):
 
     dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
     dn.verbose = False
+    dn.gram_kernel = gram
     dn.fp.A = dev(ref.A)
     dn.C = dev(C0)
     with torch.no_grad():
@@ -523,6 +547,68 @@ def test_more_than_127_neurons(M, O, K):
     Cc = rng.rand(K, 11)
     Yi = rng.rand(9, 7, 11)
     np.testing.assert_allclose(M.DeformableNMF.update_spatial(A, Cc, Yi), O.update_spatial(A, Cc, Yi), rtol=2e-5)
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_multichannel_channels_are_extra_voxels(M, O, resident):
+    """BASELINE config 5's colour channels (no reference semantics): channels share beta and C, so
+    the oracle is the reference arithmetic with every voxel sum also running over channels -- gradient of the mean
+    over batch x channels x voxels = mean of the per-channel gradients, G and r summed over channels.  Parity by
+    construction only."""
+    rng = np.random.RandomState(5)
+    sz, K, T, bs, NC = [20, 18, 2], 5, 6, 3, 3
+    P = int(np.prod(sz))
+    pos = rng.rand(K, 3) * np.array(sz)
+    colours = (0.2 + rng.rand(NC, K)).astype(np.float32)
+    video = np.maximum(rng.rand(NC, *sz, T).astype(np.float32) - 0.2, 0)      # (C,X,Y,Z,T)
+    C0 = rng.rand(K, T).astype(np.float32)
+    beta0 = O.identity_beta(T) + (rng.randn(10, 3, T) * np.array([0.5, 5e-3, 5e-3, 5e-3, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4]
+                                                                  )[:, None, None]).astype(np.float32)
+    batches = [list(range(s0, s0 + bs)) for s0 in range(0, T, bs)]
+
+    ref = O.OracleModel(sz, K, T, pos, C0=C0)
+    A_base = ref.A.copy()
+    with torch.no_grad():
+        ref.beta_param.copy_(torch.from_numpy(beta0))
+    ropt = torch.optim.Adam([ref.beta_param], lr=1e-3)
+    for times in batches:
+        g = np.zeros((10, 3, T), np.float32)
+        for c in range(NC):
+            fr = np.moveaxis(video[c][..., times], -1, 0)
+            g += O.mse_beta_grad_autograd(A_base * colours[c], ref.basis, ref.beta, sz, times, C0, fr)[1] / NC
+        ropt.zero_grad()
+        ref.beta_param.grad = torch.from_numpy(g)
+        ropt.step()
+    G = np.zeros((K, K, T))
+    r = np.zeros((K, T))
+    for c in range(NC):
+        ref.A = (A_base * colours[c]).astype(np.float32)
+        A_t, _, Yv = ref.pushforward(video[c], bs)
+        Gc, rc = O.gram_rhs(A_t, Yv)
+        G += Gc
+        r += rc
+    C_ref = O.mu_temporal_from_gram(G, r, C0, gamma=None, iters=7).astype(np.float32)
+
+    dn = M.MultiChannelDNMF(torch.tensor(sz), K, T, colours, positions=torch.from_numpy(pos).float())
+    dn.verbose = False
+    dn.fp.A = dev(A_base)
+    dn.C = dev(C0)
+    with torch.no_grad():
+        dn.fp.beta.copy_(dev(beta0))
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+    frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(video, 4, 0)))  # (T,C,X,Y,Z)
+    if resident:
+        loader = M.ResidentLoader(frames.reshape(T, -1), sz, bs)
+        assert loader.frames_2d().shape == (T, NC * P)
+    else:
+        loader = [(frames[b], torch.tensor(b)) for b in batches]
+    dn.update_motion(loader, opt, gamma=0, epochs=1)
+    assert dn.update_footprints(loader, bs, sz, gamma_c=0, iter_c=7) == (None, None, None)
+    disp = np.abs(ref.beta - beta0).max()
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - beta0, ref.beta - beta0, rtol=0, atol=2e-3 * disp)
+    np.testing.assert_allclose(dn.C.cpu().numpy(), C_ref, rtol=2e-4, atol=1e-7)
+    with pytest.raises(ValueError):
+        M.MultiChannelDNMF(torch.tensor(sz), K, T, colours[:, :2], positions=torch.from_numpy(pos).float())
 
 
 def test_config1_like_run_vs_oracle(M, O):
