@@ -258,7 +258,8 @@ class DeformableNMF:
         self.fused_motion = True
         # Gram kernel: 'dense' = K3 (every product evaluated), 'sparse' = K3s (products with an exact zero
         # skipped; same sums), 'auto' = K3s when on average fewer than half of the 16-neuron blocks of a
-        # footprint row are non-zero
+        # footprint row are non-zero, 'bf16' = K3b (every product, operands rounded to bf16: reduced precision the
+        # reference does not have, never chosen by 'auto')
         self.gram_kernel = 'auto'
         # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
         # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
@@ -398,7 +399,7 @@ class DeformableNMF:
                                                          fp.beta.detach(), order, frames, workspace=self._ws_k3)
         else:
             G, r, self._ws_k3 = ops.warp_gram_rhs(fp.packed_footprints(), fp.K, fp.sz_list, fp.beta.detach(), order,
-                                                  frames, workspace=self._ws_k3)
+                                                  frames, workspace=self._ws_k3, bf16=self.gram_kernel == 'bf16')
         return G, r
 
     def _gram_rhs_grouped(self, fp, frames, order):
@@ -425,7 +426,8 @@ class DeformableNMF:
             for j in range(i + 1, len(groups)):
                 cols = groups[i] + groups[j]
                 Gp, rp, self._ws_k3 = ops.warp_gram_rhs(fp.packed_columns(cols), len(cols), fp.sz_list, fp.beta.detach(),
-                                                        order, frames, workspace=self._ws_k3)
+                                                        order, frames, workspace=self._ws_k3,
+                                                        bf16=self.gram_kernel == 'bf16')
                 idx = torch.as_tensor(cols, device=device)
                 G[:, idx[:, None], idx[None, :]] = Gp
                 r[:, idx] = rp

@@ -27,6 +27,8 @@ SIGNATURES = {
     "dnmf_warp_gram_rhs_workspace": (_sz, [_l, _i, _i]),
     "dnmf_warp_gram_rhs": (_i, [_vp, _i, _i, _l, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz,
                                 _vp]),
+    "dnmf_warp_gram_rhs_bf16": (_i, [_vp, _i, _i, _l, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz,
+                                     _vp]),
     "dnmf_sparse_k": (_i, [_i]),
     "dnmf_pack_footprints_sparse": (_i, [_vp, _l, _i, _vp, _vp, _i, _vp, _vp]),
     "dnmf_warp_gram_rhs_sparse_workspace": (_sz, [_l, _i, _i]),

@@ -93,6 +93,25 @@ struct GramParams {
     long npatch;
 };
 
+// Voxel record of the coordinate pass: byte offsets of the NTAP footprint rows, their weights (0 outside the volume,
+// and for a voxel of a patch that sticks out of the volume) and the frame value.
+template <int NTAP>
+__device__ __forceinline__ void voxel_record(const float *bt, const Volume &vol, unsigned row_bytes,
+                                             const float *__restrict__ yb, int x, int y, int z, unsigned (&rows)[NTAP],
+                                             float (&w)[NTAP], float &yv) {
+#pragma unroll
+    for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
+    yv = 0.0f;
+    if (x < vol.X && y < vol.Y && z < vol.Z) {
+        const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
+        unsigned voxs[NTAP];
+        make_taps<NTAP>(sm, vol, w, voxs);
+#pragma unroll
+        for (int c = 0; c < NTAP; ++c) rows[c] = voxs[c] * row_bytes;
+        yv = yb[((long)x * vol.Y + y) * vol.Z + z];
+    }
+}
+
 // NTAP = 4 (Z == 1, bilinear) or 8 (trilinear).  Tap c: dx = c&1, dy = (c>>1)&1, dz = c>>2 (ATen's corner order).
 //
 // Schedule.  A k-step is {request the NTAP rows, blend them into NB fragments, NT MFMAs}.  The three
@@ -152,17 +171,8 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         }
         unsigned rows[NTAP];
         float w[NTAP];
-        float yv = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NTAP; ++c) rows[c] = 0u, w[c] = 0.0f;
-        if (x < vol.X && y < vol.Y && z < vol.Z) {
-            const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
-            unsigned voxs[NTAP];
-            make_taps<NTAP>(sm, vol, w, voxs);
-#pragma unroll
-            for (int c = 0; c < NTAP; ++c) rows[c] = voxs[c] * row_bytes;
-            yv = yb[((long)x * vol.Y + y) * vol.Z + z];
-        }
+        float yv;
+        voxel_record<NTAP>(bt, vol, row_bytes, yb, x, y, z, rows, w, yv);
         const int buf = s & 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -230,8 +240,6 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         }
     };
 
-    // one k-step: request the rows of step kk_req, then blend the fragments of the NEXT step (rows requested
-    // one step ago) in the shadow of the MFMAs of the CURRENT step, one vector instruction per MFMA gap
     // one k-step: request the rows of step kk_req (record already in registers) and fetch the record of
     // step kk_req+1, then blend the fragments of the NEXT step (rows requested one step ago) in the shadow of
     // the MFMAs of the CURRENT step, one vector instruction per MFMA gap
@@ -314,6 +322,167 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
     }
 }
 
+// K3b -- the same contraction with bf16 operands (v_mfma_f32_16x16x32_bf16, fp32 accumulate): the warped footprints
+// are blended in fp32 exactly as in K3, rounded to bf16 (round to nearest even) and multiplied on the bf16 matrix
+// pipe; the frame rides along as a bf16 column.  Not a reference precision -- BASELINE config 5 asks for it.
+//
+// Operand layout: lane l supplies A[i = l&15][k = 8(l>>4) + j], j = 0..7, and B[k][j = l&15] for the same k, so with
+// k = voxel a lane blends EIGHT voxels (8(l>>4) .. +7 of a group of 32) of its channel slot per instruction, again
+// one register set serving as both operands.  The accumulator tile is laid out like K3's, so the slab and
+// gram_finish_kernel are shared.
+//
+// A wave alternates two phases per 32 voxels: gather + blend of its 8 voxels (rows of voxel j+1 in flight while
+// voxel j is blended), then NT MFMAs.  Two waves per SIMD run the phases against each other; the gather phase is
+// the longer one (same row traffic as K3 for an eighth of the matrix-pipe time).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 t = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+    return __builtin_bit_cast(unsigned, t);
+}
+
+template <int NB, int NTAP>
+__global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_bf16_kernel(GramParams p) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NQ = NTAP / 4;
+    constexpr int NG4 = NB / 4, R = NB % 4;
+    __shared__ u32x4 s_row[4][2][NQ][K3_SS];
+    __shared__ f32x4 s_w[4][2][NQ][K3_SS];
+    __shared__ float s_y[4][2][K3_SS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)p.nchunks * p.B) return;  // whole wave leaves; no workgroup barrier below
+    const int chunk = (int)(item / p.B);
+    const int b = (int)(item - (long)chunk * p.B);
+    const int t = p.times ? p.times[b] : b;
+    const char *__restrict__ Ab = reinterpret_cast<const char *>(p.Apk + (long)b * p.a_frame_stride);
+    const float *__restrict__ yb = p.frames + (long)(p.frame_ids ? p.frame_ids[b] : b) * p.ldf;
+    const Volume vol = p.vol;
+    const unsigned row_bytes = (unsigned)p.Kp * 4u;
+
+    float bt[30];
+    load_beta(p.beta, p.T, t, bt);
+
+    const int ci = lane & 15;  // channel slot
+    const int kq = lane >> 4;  // which eight voxels of a group of 32
+    const unsigned lane_a = 16u * ci, lane_b = 256u * NG4 + 4u * R * ci;
+    const bool ylane = ci == 15;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long q_begin = (long)chunk * p.chunk_len;
+    const long q_end = q_begin + p.chunk_len < p.npatch ? q_begin + p.chunk_len : p.npatch;
+    const int nss = (int)(q_end - q_begin);
+    const int lgy = p.lgy, lgz = p.lgz, lgx = 6 - lgy - lgz;
+    int pz = (int)(q_begin % p.npz), py = (int)((q_begin / p.npz) % p.npy), px = (int)(q_begin / ((long)p.npz * p.npy));
+    const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & ((1 << lgy) - 1), lx = lane >> (lgz + lgy);
+
+    auto coord_pass = [&](int s) {
+        const int x = (px << lgx) + lx, y = (py << lgy) + ly, z = (pz << lgz) + lz;
+        if (++pz == p.npz) {
+            pz = 0;
+            if (++py == p.npy) py = 0, ++px;
+        }
+        unsigned rows[NTAP];
+        float w[NTAP];
+        float yv;
+        voxel_record<NTAP>(bt, vol, row_bytes, yb, x, y, z, rows, w, yv);
+        const int buf = s & 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            s_row[wave][buf][q][lane] = u32x4{rows[4 * q], rows[4 * q + 1], rows[4 * q + 2], rows[4 * q + 3]};
+            s_w[wave][buf][q][lane] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        }
+        s_y[wave][buf][lane] = yv;
+    };
+    auto wave_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    struct Stage {
+        RowFrag<NB> raw[NTAP];
+        f32x4 w[NQ];
+        float y;
+    };
+    // request the rows of voxel n (counted over the whole chunk, 64 per pass) of this lane's eight-voxel runs
+    auto issue = [&](int n, Stage &st) {
+        const int nc = n < nss * 16 ? n : nss * 16 - 1;  // past the end: re-read the last voxel (result unused)
+        const int buf = (nc >> 4) & 1;
+        const int vi = ((nc >> 3) & 1) * 32 + 8 * kq + (nc & 7);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const u32x4 rr = s_row[wave][buf][q][vi];
+            st.w[q] = s_w[wave][buf][q][vi];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rr[e] + lane_a, rr[e] + lane_b);
+        }
+        st.y = s_y[wave][buf][vi];
+    };
+    auto blend = [&](const Stage &st, float (&val)[NB]) {
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) val[bb] = st.raw[0].v[bb] * st.w[0][0];
+#pragma unroll
+        for (int c = 1; c < NTAP; ++c) {
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) val[bb] = fmaf(st.raw[c].v[bb], st.w[c >> 2][c & 3], val[bb]);
+        }
+        val[NB - 1] = ylane ? st.y : val[NB - 1];
+        // opaque to the vectoriser: otherwise the blends of two voxels are fused into packed-pair arithmetic (they
+        // meet in one v_cvt_pk_bf16_f32), which ties the first voxel's blend to the arrival of the second's rows
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) asm("" : "+v"(val[bb]));
+    };
+
+    Stage sa, sb;
+    unsigned frag[NB][4];
+    float va[NB], vb[NB];
+    coord_pass(0);
+    wave_fence();
+    issue(0, sa);
+    for (int s = 0; s < nss; ++s) {
+        if (s + 1 < nss) coord_pass(s + 1);
+        wave_fence();  // pass s+1 is in LDS before the look-ahead of the last voxel of pass s reads it
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int n0 = s * 16 + h * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                issue(n0 + j + 1, sb);
+                __builtin_amdgcn_sched_barrier(0);  // keep the two row sets from being requested at once
+                blend(sa, va);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(n0 + j + 2, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                blend(sb, vb);
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) frag[bb][j >> 1] = pack_bf16(va[bb], vb[bb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                const bf16x8 fi = __builtin_bit_cast(bf16x8, u32x4{frag[bi][0], frag[bi][1], frag[bi][2], frag[bi][3]});
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj) {
+                    const bf16x8 fj = __builtin_bit_cast(bf16x8, u32x4{frag[bj][0], frag[bj][1], frag[bj][2], frag[bj][3]});
+                    const int idx = tile_index(NB, bi, bj);
+                    acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fi, fj, acc[idx], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    f32x4 *out = reinterpret_cast<f32x4 *>(p.slab) + (((long)b * p.nchunks + chunk) * NT) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[(long)i * 64] = acc[i];
+}
+
 static void patch_shape(const Volume &vol, int &lgy, int &lgz, int &npy, int &npz, long &npatch) {
     lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
     lgy = vol.Z <= 2 ? 3 : 2;
@@ -335,10 +504,14 @@ static void choose_chunks(long npatch, int B, int &nchunks, long &chunk_len) {
 }
 
 template <int NB>
-static int launch_gram(GramParams p, float *G, float *r, hipStream_t st) {
+static int launch_gram(GramParams p, float *G, float *r, bool bf16, hipStream_t st) {
     const long nitems = (long)p.nchunks * p.B;
     const unsigned nwg = (unsigned)((nitems + 3) / 4);
-    if (p.vol.Z > 1)
+    if (bf16 && p.vol.Z > 1)
+        hipLaunchKernelGGL((warp_gram_bf16_kernel<NB, 8>), dim3(nwg), dim3(256), 0, st, p);
+    else if (bf16)
+        hipLaunchKernelGGL((warp_gram_bf16_kernel<NB, 4>), dim3(nwg), dim3(256), 0, st, p);
+    else if (p.vol.Z > 1)
         hipLaunchKernelGGL((warp_gram_kernel<NB, 8>), dim3(nwg), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((warp_gram_kernel<NB, 4>), dim3(nwg), dim3(256), 0, st, p);
@@ -359,9 +532,10 @@ size_t dnmf_warp_gram_rhs_workspace(long P, int K, int B) {
     return (size_t)B * (size_t)(want + 1) * (NB * (NB + 1) / 2) * 256 * sizeof(float);
 }
 
-int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z, const float *beta,
-                       int T, const int *times, int B, const float *frames, long ldf, const int *frame_ids, float *G,
-                       float *r, void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+static int gram_entry(bool bf16, const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z,
+                      const float *beta, int T, const int *times, int B, const float *frames, long ldf,
+                      const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+                      dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(Apk && beta && frames && G && r && workspace, DNMF_E_NULL, "dnmf_warp_gram_rhs: NULL buffer");
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && Kp == dnmf_padded_k(K), DNMF_E_SHAPE,
@@ -386,17 +560,32 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
     choose_chunks(p.npatch, B, p.nchunks, p.chunk_len);
     hipStream_t st = (hipStream_t)stream;
     switch (Kp / 16) {
-        case 1: return launch_gram<1>(p, G, r, st);
-        case 2: return launch_gram<2>(p, G, r, st);
-        case 3: return launch_gram<3>(p, G, r, st);
-        case 4: return launch_gram<4>(p, G, r, st);
-        case 5: return launch_gram<5>(p, G, r, st);
-        case 6: return launch_gram<6>(p, G, r, st);
-        case 7: return launch_gram<7>(p, G, r, st);
-        case 8: return launch_gram<8>(p, G, r, st);
+        case 1: return launch_gram<1>(p, G, r, bf16, st);
+        case 2: return launch_gram<2>(p, G, r, bf16, st);
+        case 3: return launch_gram<3>(p, G, r, bf16, st);
+        case 4: return launch_gram<4>(p, G, r, bf16, st);
+        case 5: return launch_gram<5>(p, G, r, bf16, st);
+        case 6: return launch_gram<6>(p, G, r, bf16, st);
+        case 7: return launch_gram<7>(p, G, r, bf16, st);
+        case 8: return launch_gram<8>(p, G, r, bf16, st);
         default:
             return fail(DNMF_E_UNSUPPORTED, "dnmf_warp_gram_rhs: K=%d needs Kp=%d > 128 (not built yet)", K, Kp);
     }
+}
+
+int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z, const float *beta,
+                       int T, const int *times, int B, const float *frames, long ldf, const int *frame_ids, float *G,
+                       float *r, void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+    return gram_entry(false, Apk, Kp, K, a_frame_stride, X, Y, Z, beta, T, times, B, frames, ldf, frame_ids, G, r,
+                      workspace, workspace_bytes, stream);
+}
+
+int dnmf_warp_gram_rhs_bf16(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z,
+                            const float *beta, int T, const int *times, int B, const float *frames, long ldf,
+                            const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+                            dnmf_stream_t stream) {
+    return gram_entry(true, Apk, Kp, K, a_frame_stride, X, Y, Z, beta, T, times, B, frames, ldf, frame_ids, G, r,
+                      workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

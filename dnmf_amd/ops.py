@@ -128,8 +128,9 @@ def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gou
     return {"recon": recon, "loss": loss, "frame_loss": frame_loss, "reg": reg, "workspace": workspace}
 
 
-def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_stride=0, workspace=None):
-    """K3.  Returns G (B,K,K), r (B,K) for the frames listed."""
+def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_stride=0, workspace=None, bf16=False):
+    """K3 (``bf16=True``: K3b, operands rounded to bf16, fp32 accumulate).  Returns G (B,K,K), r (B,K) for the
+    frames listed."""
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
     dev = Apk.device
@@ -145,8 +146,8 @@ def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_strid
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
     r = torch.empty((B, K), dtype=torch.float32, device=dev)
-    with _timed("warp_gram_rhs"):
-        rc = lib.dnmf_warp_gram_rhs(
+    with _timed("warp_gram_rhs_bf16" if bf16 else "warp_gram_rhs"):
+        rc = (lib.dnmf_warp_gram_rhs_bf16 if bf16 else lib.dnmf_warp_gram_rhs)(
             Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, beta.data_ptr(), beta.shape[2], _ptr(tt), B,
             frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
             workspace.numel() * workspace.element_size(), _stream())

@@ -106,6 +106,15 @@ int dnmf_warp_gram_rhs(const float *Apk, int Kp, int K, long a_frame_stride, int
                        const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
                        dnmf_stream_t stream);
 
+/* K3b: the same contraction on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16): warped footprints and frame are
+ * evaluated in fp32 as above, rounded to bf16 (nearest even) and accumulated in fp32.  Reduced precision that the
+ * reference does not have (it contracts in float64); offered for BASELINE config 5.  Same arguments, workspace and
+ * results layout as dnmf_warp_gram_rhs. */
+int dnmf_warp_gram_rhs_bf16(const float *Apk, int Kp, int K, long a_frame_stride, int X, int Y, int Z,
+                            const float *beta, int T, const int *times, int B, const float *frames, long ldf,
+                            const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+                            dnmf_stream_t stream);
+
 /* ---- K3s: the same contraction with exact-zero block skipping ---------------------------------------------
  * For footprints that are exactly zero over most of the volume (the reference's Gaussians underflow to 0 in
  * fp32 beyond ~30 px; multiplicative updates keep zeros).  Neurons are taken in the order `order` (K ints, sorted

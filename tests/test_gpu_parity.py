@@ -287,6 +287,57 @@ def test_random_problem_vs_oracle(M, O, sz, K, T):
     np.testing.assert_allclose(Cg.cpu().numpy(), Cref, rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("sz,K,T", [([40, 36, 3], 20, 5), ([33, 47, 1], 50, 6), ([48, 40, 2], 100, 4),
+                                    ([21, 19, 2], 10, 3), ([32, 32, 1], 120, 3), ([70, 64, 1], 100, 2)])
+def test_bf16_gram_vs_rounded_oracle(M, O, sz, K, T):
+    """K3b (BASELINE config 5's "bf16 MFMA"; SURVEY 8(c): Gram inputs rounded to bf16, fp32 accumulate).  The oracle
+    is the reference contraction on the oracle's A_t and the frame, both rounded to bf16 (nearest even): the kernel
+    must match that up to the A_t elements that sit on a rounding boundary and round the other way (the blend differs
+    from the oracle's by up to 5e-6), each of which moves its products by 2^-8 of themselves: 1e-3 of the largest
+    entry (observed 4e-4 on the 32x32 volume, where an entry is a sum over few voxels).  Against the unrounded
+    contraction the stated tolerance is 1e-2 (of the largest entry) on G, r and on C after 20 updates."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(K + 1)
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, 3.0))
+    beta = O.identity_beta(T)
+    beta += (rng.randn(10, 3, T) * np.array([0.7, 1e-2, 1e-2, 1e-2, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4, 2e-4])[:, None, None]
+             ).astype(np.float32)
+    if sz[2] == 1:
+        beta[:, 2] = O.identity_beta(T)[:, 2]
+    C = rng.rand(K, T).astype(np.float32)
+    video = rng.rand(*sz, T).astype(np.float32)
+    times = list(range(T))
+    _, A_t, _, _ = O.forward(A, O.quadratic_basis(O.voxel_lattice(sz)), beta, sz, times, C, O.trilinear_sample_torch)
+
+    def rounded(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().double().numpy()
+
+    A64 = np.transpose(A_t, [2, 3, 4, 1, 0])
+    Gb, rb = O.gram_rhs(rounded(A64), rounded(video))
+    Gx, rx = O.gram_rhs(A64.astype(np.float64), video.astype(np.float64))
+    fp = make_fp(M, sz, K, T, pos, beta=beta, A=A)
+    frames = dev(np.moveaxis(video, -1, 0)).reshape(T, -1)
+    G, r, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), times, frames, bf16=True)
+    G, r = G.cpu().numpy(), r.cpu().numpy()
+    np.testing.assert_allclose(G, np.moveaxis(Gb, 2, 0), rtol=0, atol=1e-3 * np.abs(Gb).max())
+    np.testing.assert_allclose(r, rb.T, rtol=0, atol=1e-3 * np.abs(rb).max())
+    np.testing.assert_allclose(G, np.moveaxis(Gx, 2, 0), rtol=0, atol=1e-2 * np.abs(Gx).max())
+    np.testing.assert_allclose(r, rx.T, rtol=0, atol=1e-2 * np.abs(rx).max())
+    assert np.array_equal(G, np.transpose(G, (0, 2, 1)))
+    # through the model switch, and the traces it leads to
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+    dn.fp.A = dev(A)
+    with torch.no_grad():
+        dn.fp.beta.copy_(dev(beta))
+    dn.gram_kernel = 'bf16'
+    G2, r2 = dn._gram_rhs(frames, torch.arange(T, dtype=torch.int32, device="cuda"))
+    assert np.array_equal(G2.cpu().numpy(), G) and np.array_equal(r2.cpu().numpy(), r)
+    Cb = M._mu_temporal(G2, r2, dev(C), None, 20).cpu().numpy()
+    Cx = O.mu_temporal_from_gram(Gx, rx, C, None, 20)
+    np.testing.assert_allclose(Cb, Cx, rtol=0, atol=1e-2 * np.abs(Cx).max())
+
+
 def test_full_size_properties(M):
     """512x512, K=100 (BASELINE config 3 geometry) through properties that need no CPU reference:
     identity warp => the Gram matrix of every frame is A^T A; integer translation => Gram of the shifted

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--z", type=int, default=1)
     ap.add_argument("--jitter", type=float, default=1e-3, help="random perturbation of beta (0 = identity warp)")
     ap.add_argument("--sparse", action="store_true", help="run the zero-skipping kernel K3s instead of K3")
+    ap.add_argument("--bf16", action="store_true", help="run K3b (bf16 operands) instead of K3")
     a = ap.parse_args()
     from dnmf_amd import ops
     from dnmf_amd.Demix import dNMF as M
@@ -43,7 +44,8 @@ def main():
             G, r, ws = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None,
                                                 frames, workspace=ws)
         else:
-            G, r, ws = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames, workspace=ws)
+            G, r, ws = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames, workspace=ws,
+                                         bf16=a.bf16)
         e.record()
         ev.append((s, e))
     torch.cuda.synchronize()
@@ -53,7 +55,7 @@ def main():
     flops = T * (P * K * (K + 1) + 2 * P * K + 2 * ntap * P * K)
     if a.sparse:
         print("occupancy", fp.packed_sparse()["occupancy"])
-    print(f"K3{'s' if a.sparse else ''} {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
+    print(f"K3{'s' if a.sparse else 'b' if a.bf16 else ''} {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
 
 
 if __name__ == "__main__":
