@@ -33,6 +33,7 @@ device = 'cuda'
 # update_footprints returns the reference's dense (X,Y,Z,K,T) float64 A_t only below this many bytes
 DENSE_RETURN_LIMIT = 1 << 31
 # update_motion keeps the reconstruction images of all T frames resident below this many bytes
+LISTS_BOXFRAC_LIMIT = 6.0   # 'auto' takes K3n below this mean number of footprint boxes per voxel
 RECON_CACHE_LIMIT = 64 << 30
 
 
@@ -113,6 +114,8 @@ class ExponentialFP(nn.Module):
         self._sparse_version = None
         self._sparse_pairs = None
         self._sparse_pairs_version = None
+        self._lists = None
+        self._lists_version = None
 
     @staticmethod
     def quadratic_basis(P):
@@ -178,6 +181,14 @@ class ExponentialFP(nn.Module):
             self._sparse = self._sparse_layout(self.A.contiguous(), self._zorder())
             self._sparse_version = key
         return self._sparse
+
+    def packed_lists(self):
+        """Layout of the neuron-list Gram kernel K3n (``ops.pack_footprints_lists``), rebuilt when ``A`` changes."""
+        key = (self.A.data_ptr(), self.A._version)
+        if self._lists is None or self._lists_version != key:
+            self._lists = ops.pack_footprints_lists(self.A.contiguous(), self.sz_list)
+            self._lists_version = key
+        return self._lists
 
     def packed_sparse_pairs(self, group=64):
         """K > 128: the neurons, in Z-order, are cut into groups of ``group`` and every pair of groups gets its own
@@ -256,9 +267,10 @@ class DeformableNMF:
         # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
         # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
         self.fused_motion = True
-        # Gram kernel: 'dense' = K3 (every product evaluated), 'sparse' = K3s (products with an exact zero
-        # skipped; same sums), 'auto' = K3s when on average fewer than half of the 16-neuron blocks of a
-        # footprint row are non-zero, 'bf16' = K3b (every product, operands rounded to bf16: reduced precision the
+        # Gram kernel: 'dense' = K3 (every product evaluated), 'sparse' = K3s (16-neuron blocks that are exactly zero
+        # skipped), 'lists' = K3n (only the neurons whose non-zero box a tile of voxels can reach; same sums),
+        # 'auto' = K3n while a voxel lies in few boxes, else K3s when on average fewer than half of the 16-neuron
+        # blocks of a footprint row are non-zero, else K3, 'bf16' = K3b (every product, operands rounded to bf16: reduced precision the
         # reference does not have, never chosen by 'auto')
         self.gram_kernel = 'auto'
         # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
@@ -390,7 +402,17 @@ class DeformableNMF:
         return [(self.fp, None)]
 
     def _gram_rhs_one(self, fp, frames, order):
-        """K3 or K3s on the footprints of ``fp``."""
+        """K3, K3s or K3n on the footprints of ``fp``."""
+        if self.gram_kernel in ('auto', 'lists') and fp.K <= 256:
+            ly = fp.packed_lists()
+            # K3n pays per (voxel, listed neuron) and per listed pair: it wins while a voxel lies in few boxes
+            if ly["nslot"] <= ops.LISTS_MAX_SLOTS and (self.gram_kernel == 'lists' or ly["boxfrac"] < LISTS_BOXFRAC_LIMIT):
+                G, r, self._ws_k3 = ops.warp_gram_rhs_lists(ly, fp.K, fp.sz_list, fp.beta.detach(), order, frames,
+                                                            workspace=self._ws_k3)
+                return G, r
+            if self.gram_kernel == 'lists':
+                raise ValueError(f"gram_kernel='lists': the pattern of G has {ly['nslot']} slots > "
+                                 f"{ops.LISTS_MAX_SLOTS} (footprints overlap too much)")
         if fp.K > 127:
             return self._gram_rhs_grouped(fp, frames, order)
         sp = fp.packed_sparse() if self.gram_kernel in ('auto', 'sparse') else None
@@ -603,7 +625,7 @@ class MultiChannelDNMF(DeformableNMF):
             for c in range(self.colours.shape[0]):
                 f = copy.copy(self.fp)  # shares beta (the caller's optimiser steps one tensor) and the lattice
                 f.A = self.fp.A * self.colours[c]
-                f._packed = f._sparse = f._sparse_pairs = None
+                f._packed = f._sparse = f._sparse_pairs = f._lists = None
                 self._chan_fp.append((f, slice(c * P, (c + 1) * P)))
             self._chan_key = key
         return self._chan_fp

@@ -246,6 +246,63 @@ def mu_spatial(A, A1, Cs, D=None, gamma=0.0):
     return A
 
 
+def pack_footprints_lists(A, sz):
+    """Layout of K3n: dict(At (K,P), bbox (K,6) int32, pair_slot (K,K) int32, nslot int, boxfrac) -- ``boxfrac`` is
+    the summed volume of the footprint boxes over the volume, i.e. the mean number of listed neurons per voxel."""
+    X, Y, Z = (int(s) for s in sz)
+    K = A.shape[-1]
+    A2 = _f32(A.reshape(-1, K), "A")
+    dev = A.device
+    At = torch.empty((K, A2.shape[0]), dtype=torch.float32, device=dev)
+    bbox = torch.empty((K, 6), dtype=torch.int32, device=dev)
+    pair_slot = torch.empty((K, K), dtype=torch.int32, device=dev)
+    nslot = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().dnmf_pack_footprints_lists(A2.data_ptr(), X, Y, Z, K, At.data_ptr(), bbox.data_ptr(),
+                                                      pair_slot.data_ptr(), nslot.data_ptr(), _stream()),
+               "dnmf_pack_footprints_lists")
+    bb = bbox.cpu().long()
+    ext = (bb[:, 1::2] - bb[:, 0::2] + 1).clamp_min(0)
+    return {"At": At, "bbox": bbox, "pair_slot": pair_slot, "nslot": int(nslot.item()),
+            "boxfrac": float(ext.prod(1).sum()) / (X * Y * Z)}
+
+
+LISTS_MAX_SLOTS = 3800
+# executed-work counters of the K3n launches while bench.py's TIMING is on (int64[2] tensor)
+LISTS_COUNTERS = None
+
+
+def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, workspace=None):
+    """K3n.  Returns G (B,K,K), r (B,K), workspace."""
+    global LISTS_COUNTERS
+    X, Y, Z = (int(s) for s in sz)
+    dev = beta.device
+    _f32(beta, "beta")
+    lib = _lib.load()
+    tt = _i32(times, dev) if times is not None else None
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = tt.numel() if tt is not None else (fid.numel() if fid is not None else frames.shape[0])
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("warp_gram_rhs_lists: frames must be float32 CUDA with unit inner stride")
+    nslot = layout["nslot"]
+    need = lib.dnmf_warp_gram_rhs_lists_workspace(nslot, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
+    r = torch.empty((B, K), dtype=torch.float32, device=dev)
+    counters = None
+    if TIMING is not None:
+        if LISTS_COUNTERS is None:
+            LISTS_COUNTERS = torch.zeros(2, dtype=torch.int64, device=dev)
+        counters = LISTS_COUNTERS
+    with _timed("warp_gram_rhs_lists"):
+        rc = lib.dnmf_warp_gram_rhs_lists(
+            layout["At"].data_ptr(), layout["bbox"].data_ptr(), layout["pair_slot"].data_ptr(), nslot, K, X, Y, Z,
+            beta.data_ptr(), beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(),
+            r.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())
+    _lib.check(rc, "dnmf_warp_gram_rhs_lists")
+    return G, r, workspace
+
+
 class Communicator:
     """C1: the library's RCCL communicator over the ranks of a ``torch.distributed`` group (one process per GPU).
 

@@ -144,6 +144,27 @@ int dnmf_warp_gram_rhs_sparse_lt(const float *Aps, int Ks, int K, const int *ord
                                  void *workspace, size_t workspace_bytes, unsigned long long *counters,
                                  dnmf_stream_t stream);
 
+/* ---- K3n: the same contraction neuron by neuron, for compact footprints ---------------------------------------
+ * When every footprint is non-zero only inside a small box (the reference's Gaussians: ~61 px wide), almost all of
+ * A_t^T A_t is a sum of products with an exact zero.  This kernel evaluates, per tile of 256 voxels, only the neurons
+ * whose box the tile's taps can reach, on the vector ALU; sums are those of dnmf_warp_gram_rhs up to the order of
+ * fp32 additions and are deterministic.  K <= 256.
+ * dnmf_pack_footprints_lists: At (K,P) <- A (P,K) transposed; bbox (K,6) int32 = xlo,xhi,ylo,yhi,zlo,zhi of the
+ *   non-zeros of each footprint; pair_slot (K,K) int32 and *nslot (one int32, DEVICE) = the static pattern of G:
+ *   slots [0,K) hold r, the following ones the pairs (k,l) whose boxes can meet under one tap cell, the last one
+ *   (nslot-1) collects everything else.  The caller reads *nslot back once to size the workspace.
+ * dnmf_warp_gram_rhs_lists: other arguments and results as dnmf_warp_gram_rhs (G dense (B,K,K), r (B,K));
+ *   nslot <= 3800 (DNMF_E_UNSUPPORTED beyond: the footprints overlap too much, use K3 / K3s);
+ *   workspace: dnmf_warp_gram_rhs_lists_workspace(nslot,B) bytes;
+ *   counters: NULL, or 2 x uint64 INCREMENTED by the (tile, neuron) evaluations and the (tile, pair) sums done. */
+int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float *At, int *bbox, int *pair_slot,
+                               int *nslot, dnmf_stream_t stream);
+size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int B);
+int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, int nslot, int K, int X, int Y,
+                             int Z, const float *beta, int T, const int *times, int B, const float *frames, long ldf,
+                             const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+                             unsigned long long *counters, dnmf_stream_t stream);
+
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
  * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.

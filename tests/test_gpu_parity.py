@@ -497,6 +497,59 @@ def test_demo_loop_recovers_traces(M, capsys):
     assert 0.15 < float(line.split("median")[1]) < 0.35, line
 
 
+@pytest.mark.parametrize("sz,K,T,sigma", [([64, 48, 1], 30, 5, 1.0), ([70, 50, 1], 100, 4, 0.8), ([40, 33, 2], 20, 3, 1.2),
+                                          ([24, 40, 5], 40, 3, 0.9), ([33, 47, 1], 50, 4, 3.0), ([96, 80, 1], 200, 3, 0.7),
+                                          ([16, 16, 1], 3, 2, 3.0), ([48, 40, 3], 70, 2, 3.0)])
+def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma):
+    """K3n against K3 on the same inputs: narrow footprints (short lists, empty tiles), the reference's sigma = 3 on
+    small volumes (every neuron listed everywhere: groups of 6 and the cross-group path), 2-D and 3-D tiles, ragged
+    volume edges, K up to 200 (four list words), warps that push part of the volume outside.  Sums agree to fp32
+    summation order; the pattern of exact zeros of G is the dense kernel's; two launches agree bitwise."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(K + sz[0])
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, sigma))
+    A[A < 1e-6] = 0          # compact support, as fp32 underflow gives at the reference's scale
+    A[..., K - 1] = 0        # one neuron without any non-zero
+    beta = O.identity_beta(T)
+    beta += (rng.randn(10, 3, T) * np.array([2.0, 2e-2, 2e-2, 2e-2, 3e-4, 3e-4, 3e-4, 3e-4, 3e-4, 3e-4])[:, None, None]
+             ).astype(np.float32)
+    if sz[2] == 1:
+        beta[:, 2] = O.identity_beta(T)[:, 2]
+    fp = make_fp(M, sz, K, T, pos, beta=beta, A=A)
+    frames = torch.rand(T, int(np.prod(sz)), device="cuda")
+    ly = fp.packed_lists()
+    bb = ly["bbox"].cpu().numpy()
+    nz = A.reshape(-1, K) != 0
+    lat = O.voxel_lattice(sz).reshape(-1, 3)
+    for k in (0, K // 2, K - 1):
+        if nz[:, k].any():
+            ref = np.stack([lat[nz[:, k]].min(0), lat[nz[:, k]].max(0)], 1).reshape(-1)
+            assert np.array_equal(bb[k], ref.astype(np.int32))
+        else:
+            assert all(bb[k, 2 * d] > bb[k, 2 * d + 1] for d in range(3))
+    np.testing.assert_array_equal(ly["At"].cpu().numpy(), A.reshape(-1, K).T)
+    if K < 128:
+        Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames)
+    else:
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+        dn.fp, dn.gram_kernel = fp, 'dense'
+        Gd, rd = dn._gram_rhs(frames, torch.arange(T, dtype=torch.int32, device="cuda"))
+    Gn, rn, ws = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames)
+    assert float((Gn - Gd).abs().max()) < 2e-6 * float(Gd.abs().max())
+    assert float((rn - rd).abs().max()) < 2e-6 * float(rd.abs().max())
+    assert torch.equal(Gn, Gn.transpose(1, 2))
+    assert torch.equal(Gn == 0, Gd == 0) or float(Gd[(Gn == 0) != (Gd == 0)].abs().max()) < 1e-30
+    G2, r2, _ = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames, workspace=ws)
+    assert torch.equal(G2, Gn) and torch.equal(r2, rn)
+    # a subset of frames in another order, through the model switch
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+    dn.fp, dn.gram_kernel = fp, 'lists'
+    order = torch.tensor([T - 1, 0], dtype=torch.int32, device="cuda")
+    G3, r3 = dn._gram_rhs(frames[order.long()].contiguous(), order)
+    assert torch.equal(G3, Gn[order.long()]) and torch.equal(r3, rn[order.long()])
+
+
 @pytest.mark.parametrize("variant", ["table", "static"])
 @pytest.mark.parametrize("sz,K,T,sigma", [([96, 80, 1], 40, 5, 1.0), ([64, 48, 2], 100, 3, 0.7), ([40, 36, 3], 20, 4, 3.0),
                                           ([33, 47, 1], 7, 6, 0.8), ([32, 32, 1], 100, 3, 3.0), ([48, 40, 2], 80, 3, 1.6)])

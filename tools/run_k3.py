@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--jitter", type=float, default=1e-3, help="random perturbation of beta (0 = identity warp)")
     ap.add_argument("--sparse", action="store_true", help="run the zero-skipping kernel K3s instead of K3")
     ap.add_argument("--bf16", action="store_true", help="run K3b (bf16 operands) instead of K3")
+    ap.add_argument("--lists", action="store_true", help="run the neuron-list kernel K3n instead of K3")
     a = ap.parse_args()
     from dnmf_amd import ops
     from dnmf_amd.Demix import dNMF as M
@@ -39,7 +40,10 @@ def main():
     for _ in range(a.reps):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        if a.sparse:
+        if a.lists:
+            ly = fp.packed_lists()
+            G, r, ws = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames, workspace=ws)
+        elif a.sparse:
             sp = fp.packed_sparse()
             G, r, ws = ops.warp_gram_rhs_sparse(sp["Aps"], K, sp["order"], sp["row_mask"], sz, fp.beta.detach(), None,
                                                 frames, workspace=ws)
@@ -55,7 +59,9 @@ def main():
     flops = T * (P * K * (K + 1) + 2 * P * K + 2 * ntap * P * K)
     if a.sparse:
         print("occupancy", fp.packed_sparse()["occupancy"])
-    print(f"K3{'s' if a.sparse else 'b' if a.bf16 else ''} {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
+    if a.lists:
+        print("nslot", fp.packed_lists()["nslot"], "boxfrac", fp.packed_lists()["boxfrac"])
+    print(f"K3{'n' if a.lists else 's' if a.sparse else 'b' if a.bf16 else ''} {sz} K={K} T={T}: ms per launch {['%.2f' % m for m in ms]}  -> {flops / (min(ms) * 1e-3) / 1e12:.1f} TFLOP/s algorithmic")
 
 
 if __name__ == "__main__":
