@@ -13,7 +13,7 @@ T=4000, K=100, fp32.  N>1: the T axis is sharded, every rank holds 4000 frames o
 barrier.  The video is generated on the GPU before the timed region starts (inputs resident in HBM).
 
 Rank 0 prints ONE JSON line; it also carries
-  roofline      the dominant kernel (the Gram kernel K3s / K3, fp32 MFMA) timed with HIP events on its stream
+  roofline      the dominant kernel (the Gram kernel K3n / K3s / K3) timed with HIP events on its stream
   cpu_baseline  the CPU oracle (reference op sequence) timed on this host on a bounded sample, N=1 only
 """
 import argparse
@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak (spec)
+HBM_PEAK_GBS = 8000.0         # same guide: HBM3E ~8 TB/s
 
 
 def parse():
@@ -44,8 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--gram", choices=["auto", "dense", "sparse"], default="auto",
-                    help="Gram kernel: K3 (dense), K3s (exact-zero blocks skipped) or by footprint occupancy")
+    ap.add_argument("--gram", choices=["auto", "dense", "sparse", "lists"], default="auto",
+                    help="Gram kernel: K3 (dense), K3s (exact-zero blocks skipped), K3n (neuron lists) or by footprint shape")
     return ap.parse_args()
 
 
@@ -147,8 +148,9 @@ def main():
         ops.warp_gram_rhs(dn.fp.packed_footprints(), K, sz, dn.fp.beta.detach(), [0], frames)
     fence()
     ops.TIMING = {}
-    if ops.SPARSE_COUNTERS is not None:
-        ops.SPARSE_COUNTERS.zero_()
+    for counters in (ops.SPARSE_COUNTERS, ops.LISTS_COUNTERS):
+        if counters is not None:
+            counters.zero_()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -175,9 +177,10 @@ def main():
     if rank == 0:
         def evs(name):
             return [a.elapsed_time(b) * 1e-3 for a, b in timing.get(name, [])]
-        k3d, k3s, k2 = evs("warp_gram_rhs"), evs("warp_gram_rhs_sparse"), evs("warp_recon_grad")
-        sparse = len(k3s) > 0
-        k3 = k3s if sparse else k3d
+        k3d, k3s, k3n, k2 = (evs("warp_gram_rhs"), evs("warp_gram_rhs_sparse"), evs("warp_gram_rhs_lists"),
+                             evs("warp_recon_grad"))
+        lists, sparse = len(k3n) > 0, len(k3s) > 0
+        k3 = k3n if lists else (k3s if sparse else k3d)
         k3_avg = sum(k3) / max(1, len(k3))
         # algorithmic flops of one Gram launch when every product is evaluated (symmetric Gram,
         # rhs, 4 bilinear taps)
@@ -187,7 +190,24 @@ def main():
         if os.path.exists(tpath):
             tjson = json.load(open(tpath))
         key = f"{size}x{size}x{T_loc}_K{K}"
-        if sparse:
+        if lists:
+            # K3n has no matrix-pipe work; its floor is the traffic it cannot avoid: every frame once, the footprints
+            # once (they stay in L2 / MALL across frames), G and r once
+            abytes = 4.0 * P * T_loc + 4.0 * P * K + 4.0 * T_loc * (K * K + K)
+            n_eval, n_pair = (float(v) / len(k3n) for v in ops.LISTS_COUNTERS.tolist())
+            roof = {"kernel": "warp_gram_lists_kernel<4,2> (K3n: per 256-voxel tile only the neurons whose non-zero box "
+                              "the tile's taps reach; vector ALU, no MFMA)",
+                    "bound": "hbm", "achieved": abytes / k3_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": abytes / k3_avg / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(key + "_lists"),
+                    "launch_ms": 1e3 * k3_avg, "launches": len(k3n), "bytes_per_launch": abytes,
+                    "count": "algorithmic bytes = frames 4PT + footprints 4PK (once per launch) + G, r 4T(K^2+K); the "
+                             "kernel is bound by vector-ALU issue of the reference's fp32 coordinate sequence (~140 "
+                             "instructions per voxel, evaluated once per voxel), see valu_issue",
+                    "valu_issue": tjson.get(key + "_lists_valu"),
+                    "tile_neuron_evaluations_per_launch": n_eval, "tile_pair_sums_per_launch": n_pair,
+                    "dense_equivalent_flops_per_launch": dense_flops,
+                    "dense_equivalent_tflops": dense_flops / k3_avg / 1e12}
+        elif sparse:
             # flops of the products that were not skipped, from the kernel's own counters: an MFMA is
             # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (4 taps + rhs) FMAs
             n_mfma, n_blend = (float(v) / len(k3s) for v in ops.SPARSE_COUNTERS.tolist())
@@ -220,7 +240,8 @@ def main():
             "config": {"workload": f"Simulator {size}x{size}x{T_total} (Z=1), K={K}, fp32: update_motion(epochs=1, "
                                    f"batch {bs}, Adam lr 1e-5) + update_footprints(iter_c={args.iter_c}, gamma_c=0)",
                        "frames_per_gpu": T_loc, "parallelism": f"frames sharded over {world} GPU(s), no collective",
-                       "gram_kernel": dn.gram_kernel + (" -> zero-skipping" if sparse else " -> dense")},
+                       "gram_kernel": dn.gram_kernel + (" -> neuron lists (K3n)" if lists else
+                                                        " -> zero-skipping blocks (K3s)" if sparse else " -> dense (K3)")},
             "roofline": roof,
             "roofline_dense_kernel": {
                 "kernel": "warp_gram_kernel<7,4> (K3): every product evaluated, one launch outside the timed region",
