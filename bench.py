@@ -50,6 +50,18 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(size, K, batch, iter_c, positions0, frames_host):
     """The oracle's faithful restatement of the reference sweep on a bounded sample of the same workload."""
     from oracle import dnmf_oracle as O
@@ -86,9 +98,12 @@ def cpu_baseline(size, K, batch, iter_c, positions0, frames_host):
 
 def main():
     args = parse()
+    # torch sizes its CPU thread pool by the host's core count; under a smaller cgroup quota every CPU op then gets
+    # the process throttled for most of a 100 ms scheduler period -- longer than a sweep takes on the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // world)))  # the ranks share the quota
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev_index = local_rank % torch.cuda.device_count()

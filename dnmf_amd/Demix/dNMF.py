@@ -116,6 +116,7 @@ class ExponentialFP(nn.Module):
         self._sparse_pairs_version = None
         self._lists = None
         self._lists_version = None
+        self.use_lists = True   # reconstruction image from neuron lists when the footprints are compact
 
     @staticmethod
     def quadratic_basis(P):
@@ -138,7 +139,12 @@ class ExponentialFP(nn.Module):
         return ops.pack_footprints(sub)
 
     def recon_image(self, C, times, out=None):
-        """S[b] = A . C[:, times[b]] (``dnmf_recon_image``), by groups of 112 neurons when K > 127."""
+        """S[b] = A . C[:, times[b]]: from the neuron lists when the footprints are compact (``use_lists``), else
+        ``dnmf_recon_image`` (fp32 MFMA), by groups of 112 neurons when K > 127."""
+        if self.use_lists and self.K <= 256:
+            ly = self.packed_lists()
+            if ly["boxfrac"] < LISTS_BOXFRAC_LIMIT:
+                return ops.recon_image_lists(ly, self.K, self.sz_list, C, times, out=out)
         if self.K <= 127:
             return ops.recon_image(self.packed_footprints(), self.K, C, times, out=out)
         for n, s0 in enumerate(range(0, self.K, 112)):
@@ -264,6 +270,7 @@ class DeformableNMF:
             self.D = None
         self._ws_k2 = None
         self._ws_k3 = None
+        self._S_bufs = None
         # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
         # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
         self.fused_motion = True
@@ -465,9 +472,12 @@ class DeformableNMF:
             return None
         C = self.C.to(device, torch.float32).contiguous()
         all_t = torch.arange(fp0.T, dtype=torch.int32, device=device)
+        # the buffers are kept between calls: re-allocating gigabytes every epoch makes the caching allocator split and
+        # re-map its large blocks (tens of milliseconds every few sweeps)
+        if self._S_bufs is None or len(self._S_bufs) != len(chans) or self._S_bufs[0].shape != (fp0.T, lds):
+            self._S_bufs = [torch.empty((fp0.T, lds), dtype=torch.float32, device=device) for _ in chans]
         out = []
-        for fp, _ in chans:
-            S = torch.empty((fp.T, lds), dtype=torch.float32, device=device)
+        for (fp, _), S in zip(chans, self._S_bufs):
             for s in range(0, fp.T, 32768):
                 fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768])
             out.append(S)

@@ -1,0 +1,146 @@
+// Reconstruction image S[b,p] = sum_k C[k,t_b] A[p,k] for COMPACT footprints, from the neuron-major copy At (K,P)
+// and the boxes of dnmf_pack_footprints_lists.
+//
+// Same role as recon_image.hip (the reference's einsum of Demix/dNMF.py:58, taken before the warp because the
+// gather is linear).  A tile of 4 x 64 voxels (64 lanes along the contiguous axis, so a wave stores 256-byte runs)
+// needs only the neurons whose non-zero box meets it: a static list.  The wave keeps their footprint values for its
+// four voxels per lane in registers and sweeps a run of frames: per frame and lane 4 x (listed neurons) FMAs and
+// four stores -- the kernel is bound by writing S.
+//
+// Terms with an exact zero factor are the only ones dropped, so S equals the dense product up to the order of the
+// fp32 additions (ascending neuron index here).
+#include "common.hpp"
+
+namespace dnmf {
+
+constexpr int RL_NG = 8;  // neurons held in registers at a time
+
+template <int NW>
+__global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restrict__ At, const int *__restrict__ bbox,
+                                                          int K, Volume vol, const float *__restrict__ C, long ldc,
+                                                          const int *__restrict__ times, int B, float *__restrict__ S,
+                                                          long lds, int nu, int frames_per_wave) {
+    __shared__ int s_list[4][64 * NW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;                       // (x group, run of 64 positions of the (y,z) plane)
+    const int b0 = (blockIdx.y * 4 + wave) * frames_per_wave;
+    if (b0 >= B) return;                               // whole wave leaves; no workgroup barrier below
+    const int b1 = min(b0 + frames_per_wave, B);
+    const int YZ = vol.Y * vol.Z;
+    const int qu = tile % nu, qx = tile / nu;
+    const int u = 64 * qu + lane;                      // position in the (y,z) plane
+    const bool uin = u < YZ;
+    const int x0 = 4 * qx;
+    // box of the tile
+    const int ylo = (64 * qu) / vol.Z, yhi = min(64 * qu + 63, YZ - 1) / vol.Z;
+    const int xlo = x0, xhi = min(x0 + 3, vol.X - 1);
+
+    int *lst = s_list[wave];
+    int n = 0;
+#pragma unroll
+    for (int wd = 0; wd < NW; ++wd) {
+        const int k = lane + 64 * wd;
+        bool hit = false;
+        if (k < K) {
+            const int *bb = bbox + k * 6;
+            hit = bb[0] <= xhi && bb[1] >= xlo && bb[2] <= yhi && bb[3] >= ylo && bb[4] <= bb[5];
+        }
+        const unsigned long long m = __ballot(hit);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (hit) lst[n + before] = k;
+        n += __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float *__restrict__ out = S + (long)x0 * YZ + u;
+    if (n == 0) {
+        for (int b = b0; b < b1; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (uin && x0 + v < vol.X) out[(long)b * lds + (long)v * YZ] = 0.0f;
+        return;
+    }
+    for (int g = 0; g < n; g += RL_NG) {
+        // footprint values of this group at the lane's voxels (0 beyond the list / outside the volume)
+        const int mine = lst[min(g + (lane & 7), n - 1)];
+        int ks[RL_NG];
+        float a[RL_NG][4];
+#pragma unroll
+        for (int i = 0; i < RL_NG; ++i) {
+            ks[i] = g + i < n ? __builtin_amdgcn_readlane(mine, i) : -1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[i][v] = 0.0f;
+            if (ks[i] >= 0) {
+                const float *__restrict__ Ak = At + (long)ks[i] * vol.P + (long)x0 * YZ + u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (uin && x0 + v < vol.X) a[i][v] = Ak[(long)v * YZ];
+            }
+        }
+        // frames in runs of 64: lane j fetches the traces of frame bb + j, the run then reads them as scalars
+        for (int bb = b0; bb < b1; bb += 64) {
+            const int bl = min(bb + lane, b1 - 1);
+            const int tcol = times ? times[bl] : bl;
+            float cv[RL_NG];
+#pragma unroll
+            for (int i = 0; i < RL_NG; ++i) cv[i] = ks[i] >= 0 ? C[(long)ks[i] * ldc + tcol] : 0.0f;
+            const int nb = min(64, b1 - bb);
+            for (int j = 0; j < nb; ++j) {
+                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float *__restrict__ dst = out + (long)(bb + j) * lds;
+                if (g > 0) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (uin && x0 + v < vol.X) s[v] = dst[(long)v * YZ];
+                }
+#pragma unroll
+                for (int i = 0; i < RL_NG; ++i) {
+                    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[i]), j));
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s[v] = fmaf(a[i][v], c, s[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (uin && x0 + v < vol.X) dst[(long)v * YZ] = s[v];
+            }
+        }
+    }
+}
+
+}  // namespace dnmf
+
+extern "C" {
+
+int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
+                           const int *times, int B, float *S, long lds, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(At && bbox && C && S, DNMF_E_NULL, "dnmf_recon_image_lists: NULL buffer");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && B > 0, DNMF_E_SHAPE, "dnmf_recon_image_lists: X=%d Y=%d Z=%d K=%d B=%d",
+                 X, Y, Z, K, B);
+    DNMF_REQUIRE(K <= 256, DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: K=%d > 256", K);
+    const Volume vol = make_volume(X, Y, Z);
+    DNMF_REQUIRE(lds >= vol.P, DNMF_E_SHAPE, "dnmf_recon_image_lists: lds=%ld < P=%ld", lds, vol.P);
+    const int nu = (int)(((long)Y * Z + 63) / 64);
+    const long ntile = (long)((X + 3) / 4) * nu;
+    DNMF_REQUIRE(ntile < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: %ld tiles", ntile);
+    // frames per wave: enough waves to fill the chip (>= 16k), long enough runs to amortise the footprint loads
+    int fpw = (int)(((long)B * ntile + 16383) / 16384);
+    fpw = fpw < 16 ? 16 : fpw;
+    fpw = fpw > B ? B : fpw;
+    const int ny = (B + 4 * fpw - 1) / (4 * fpw);
+    DNMF_REQUIRE(ny <= 65535, DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: B=%d too large", B);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ntile, (unsigned)ny);
+    if (K <= 64)
+        hipLaunchKernelGGL(recon_lists_kernel<1>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+    else if (K <= 128)
+        hipLaunchKernelGGL(recon_lists_kernel<2>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+    else
+        hipLaunchKernelGGL(recon_lists_kernel<4>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+    return check_launch("dnmf_recon_image_lists");
+}
+
+}  // extern "C"

@@ -93,6 +93,26 @@ def recon_image(Apk: torch.Tensor, K: int, C: torch.Tensor, times, out: torch.Te
     return out
 
 
+def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
+    """S as ``recon_image`` from the K3n layout (``pack_footprints_lists``): compact footprints, static tile lists."""
+    X, Y, Z = (int(s) for s in sz)
+    P = X * Y * Z
+    _f32(C, "C")
+    tt = _i32(times, C.device)
+    B = tt.numel()
+    lds = (P + 3) // 4 * 4
+    if out is None:
+        out = torch.empty((B, lds), dtype=torch.float32, device=C.device)
+    if out.shape[0] < B or out.stride(0) < P or out.stride(1) != 1:
+        raise ValueError("recon_image_lists: out must be (>=B, ld) with ld >= P")
+    with _timed("recon_image_lists"):
+        rc = _lib.load().dnmf_recon_image_lists(layout["At"].data_ptr(), layout["bbox"].data_ptr(), K, X, Y, Z,
+                                                C.data_ptr(), C.stride(0), tt.data_ptr(), B, out.data_ptr(),
+                                                out.stride(0), _stream())
+    _lib.check(rc, "dnmf_recon_image_lists")
+    return out
+
+
 def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gout=None, want_recon=False,
                     want_loss=True, want_reg=True, workspace=None, norm_frames=0):
     """K2.  S (>=B, lds) recon images, frames (>=B, ldf) or None with gout (B,P).

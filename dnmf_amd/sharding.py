@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 
 
@@ -39,24 +40,27 @@ class EpochPlan:
 
 def plan_epoch(perm: torch.Tensor, batch_size: int, t0: int, t1: int) -> EpochPlan:
     """Split the global frame order ``perm`` (1-D int64, a permutation of 0..T_total-1 or any visiting order)
-    into mini-batches of ``batch_size`` and keep what belongs to the block [t0, t1)."""
-    perm = perm.to(torch.int64).cpu()
-    n_total = perm.numel()
+    into mini-batches of ``batch_size`` and keep what belongs to the block [t0, t1).
+
+    numpy on purpose: these are a few thousand elements, and torch's CPU kernels would wake its whole intra-op
+    thread pool once per epoch -- on a host whose CPU quota is smaller than its core count that gets the process
+    throttled for most of a scheduler period, longer than the epoch itself takes on the GPU."""
+    perm = perm.to(torch.int64).cpu().numpy()
+    n_total = perm.size
     nsteps = (n_total + batch_size - 1) // batch_size
-    step_of_pos = torch.arange(n_total, dtype=torch.int64) // batch_size
-    size_of_step = torch.full((nsteps,), batch_size, dtype=torch.int64)
-    if n_total % batch_size:
-        size_of_step[-1] = n_total % batch_size
+    step_of_pos = np.arange(n_total, dtype=np.int64) // batch_size
+    tail = n_total % batch_size
     mine = (perm >= t0) & (perm < t1)
     local = perm[mine] - t0
     steps = step_of_pos[mine]            # non-decreasing: positions are visited in order
-    frame_step = torch.full((t1 - t0,), -1, dtype=torch.int32)
-    frame_step[local] = steps.to(torch.int32)
-    sizes = size_of_step[steps]
-    groups = [(local[sizes == s], int(s)) for s in sorted(set(size_of_step.tolist()), reverse=True)]
+    frame_step = np.full((t1 - t0,), -1, dtype=np.int32)
+    frame_step[local] = steps.astype(np.int32)
+    sizes = np.where(steps == nsteps - 1, tail if tail else batch_size, batch_size)
+    groups = [(torch.from_numpy(local[sizes == s]), int(s)) for s in sorted({batch_size, tail or batch_size}, reverse=True)]
     groups = [g for g in groups if g[0].numel()]
-    counts = torch.bincount(steps, minlength=nsteps).tolist()
-    return EpochPlan(nsteps=nsteps, frame_step=frame_step, groups=groups, batches=_LazySplit(local, counts))
+    counts = np.bincount(steps, minlength=nsteps).tolist()
+    return EpochPlan(nsteps=nsteps, frame_step=torch.from_numpy(frame_step), groups=groups,
+                     batches=_LazySplit(torch.from_numpy(local), counts))
 
 
 class _LazySplit:

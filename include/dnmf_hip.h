@@ -165,6 +165,11 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
                              const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
                              unsigned long long *counters, dnmf_stream_t stream);
 
+/* Reconstruction image from the K3n layout: S as dnmf_recon_image, summing per tile of 4 x 64 voxels only the neurons
+ * whose box meets the tile (static lists); bound by writing S.  K <= 256. */
+int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
+                           const int *times, int B, float *S, long lds, dnmf_stream_t stream);
+
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
  * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.

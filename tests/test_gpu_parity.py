@@ -550,6 +550,32 @@ def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma):
     assert torch.equal(G3, Gn[order.long()]) and torch.equal(r3, rn[order.long()])
 
 
+@pytest.mark.parametrize("sz,K,sigma", [([64, 48, 1], 30, 1.0), ([70, 130, 1], 100, 0.8), ([40, 33, 2], 20, 1.2),
+                                        ([24, 40, 5], 40, 0.9), ([33, 47, 1], 50, 3.0), ([96, 80, 1], 200, 0.7),
+                                        ([5, 7, 3], 3, 3.0)])
+def test_recon_image_from_lists(M, O, sz, K, sigma):
+    """S = A.C from the neuron lists against float64 on the host: short lists, lists longer than the eight register
+    slots (read-modify-write of S), ragged tiles, 3-D volumes, K = 200, a frame subset in another order, a padded
+    row stride."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(K)
+    T = 70
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, sigma))
+    A[A < 1e-6] = 0
+    A[..., 0] = 0
+    C = rng.rand(K, T).astype(np.float32)
+    P = int(np.prod(sz))
+    ly = ops.pack_footprints_lists(dev(A), sz)
+    times = rng.permutation(T)[:67]
+    lds = (P + 3) // 4 * 4 + 8
+    out = torch.full((len(times), lds), -1.0, device="cuda")
+    S = ops.recon_image_lists(ly, K, sz, dev(C), times, out=out)
+    ref = A.reshape(P, K).astype(np.float64) @ C[:, times].astype(np.float64)
+    np.testing.assert_allclose(S[:, :P].cpu().numpy(), ref.T, rtol=1e-5, atol=1e-6)
+    assert bool((S[:, P:] == -1.0).all())
+
+
 @pytest.mark.parametrize("variant", ["table", "static"])
 @pytest.mark.parametrize("sz,K,T,sigma", [([96, 80, 1], 40, 5, 1.0), ([64, 48, 2], 100, 3, 0.7), ([40, 36, 3], 20, 4, 3.0),
                                           ([33, 47, 1], 7, 6, 0.8), ([32, 32, 1], 100, 3, 3.0), ([48, 40, 2], 80, 3, 1.6)])

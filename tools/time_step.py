@@ -47,3 +47,19 @@ for label, timing in (("plain", None), ("with ops.TIMING", {})):
     torch.cuda.synchronize()
     print("5 sweeps %-16s %.2f ms each" % (label, 1e3 * (time.perf_counter() - t0) / 5))
 ops.TIMING = None
+for label, sync in (("sync each sweep", True), ("no sync", False)):
+    ts = []
+    torch.cuda.synchronize(); t00 = time.perf_counter()
+    for _ in range(8):
+        t0 = time.perf_counter(); sweep()
+        if sync:
+            torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    print(label, ["%.1f" % t for t in ts], "total %.1f ms" % (1e3 * (time.perf_counter() - t00)))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5):
+    sweep()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
