@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/sec demixed on the WUtils.Simulator video, 512x512xT, K=100.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,9 @@ HBM_PEAK_GBS = 8000.0         # same guide: HBM3E ~8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # a sweep takes ~10 ms; the first few after an idle period run ~30 % slower (clock ramp), hence the defaults
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512, help="X = Y (Z = 1)")
     ap.add_argument("--frames", type=int, default=4000, help="frames per GPU")
     ap.add_argument("--neurons", type=int, default=100)

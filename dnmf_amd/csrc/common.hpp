@@ -26,6 +26,8 @@ struct Volume {
     long P;
     float sx1, sy1, sz1;  // (S-1) as fp32, the divisor of Demix/dNMF.py:55 (sz is int64 there)
     float rcp_yz, rcp_z;  // 1/(Y*Z), 1/Z for the voxel-index split
+    float rx1, ry1, rz1;  // RN(1/(S-1)) for the division shortcut of normalise_fast
+    int fastdiv;          // every divided axis has 1 <= S-1 <= 65535: the shortcut is exact (tools/check_fastdiv.c)
 };
 
 inline Volume make_volume(int X, int Y, int Z) {
@@ -34,6 +36,8 @@ inline Volume make_volume(int X, int Y, int Z) {
     v.P = (long)X * Y * Z;
     v.sx1 = (float)(X - 1), v.sy1 = (float)(Y - 1), v.sz1 = (float)(Z - 1);
     v.rcp_yz = 1.0f / ((float)Y * (float)Z), v.rcp_z = 1.0f / (float)Z;
+    v.rx1 = X > 1 ? 1.0f / v.sx1 : 0.0f, v.ry1 = Y > 1 ? 1.0f / v.sy1 : 0.0f, v.rz1 = Z > 1 ? 1.0f / v.sz1 : 0.0f;
+    v.fastdiv = X > 1 && X <= 65536 && Y > 1 && Y <= 65536 && Z <= 65536;  // Z == 1: z is never divided
     return v;
 }
 
@@ -66,6 +70,26 @@ __device__ __forceinline__ float normalise(float q, float sm1) {
     return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, q), sm1), 1.0f);
 }
 
+// The same value with the division by the constant S-1 done as a multiplication by r = RN(1/(S-1)) and one
+// correction step: q0 = RN(a r), e = RN(a - q0 (S-1)) (exact), RN(q0 + e r).  For the integer divisors 1..65535 this
+// is the correctly rounded quotient for every normal fp32 a -- checked exhaustively over all 2^23 significands per
+// divisor by tools/check_fastdiv.c; both sequences scale with powers of two, and a quotient too small to be normal
+// rounds to n = -1 either way.  Non-finite a gives a non-finite result in both (inf vs NaN), which every caller
+// turns into zero weights.  Three instructions instead of the ~12 of the IEEE division sequence.
+__device__ __forceinline__ float normalise_fast(float q, float sm1, float rcp) {
+    const float a = __fmul_rn(2.0f, q);
+    const float q0 = __fmul_rn(a, rcp);
+    const float e = __fmaf_rn(-q0, sm1, a);
+    return __fsub_rn(__fmaf_rn(e, rcp, q0), 1.0f);
+}
+
+// n along axis d of the volume (0, 1, 2), by the shortcut when the volume allows it (wave-uniform choice)
+__device__ __forceinline__ float normalise_axis(float q, const Volume &vol, int d) {
+    const float sm1 = d == 0 ? vol.sx1 : (d == 1 ? vol.sy1 : vol.sz1);
+    const float rcp = d == 0 ? vol.rx1 : (d == 1 ? vol.ry1 : vol.rz1);
+    return vol.fastdiv ? normalise_fast(q, sm1, rcp) : normalise(q, sm1);
+}
+
 // torch grid_sampler_unnormalize, align_corners=True: ((n + 1) / 2) * (S - 1), fp32, no contraction.
 // The round trip normalise -> unnormalise decides floor() for on-lattice points (hard part 1).
 __device__ __forceinline__ float unnormalise(float n, float sm1) {
@@ -88,12 +112,12 @@ template <bool HASZ>
 __device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vol, int xi, int yi, int zi) {
     const float x = (float)xi, y = (float)yi, z = HASZ ? (float)zi : 0.0f;
     Sample s;
-    s.ux = unnormalise(normalise(poly_q(b, 0, x, y, z), vol.sx1), vol.sx1);
-    s.uy = unnormalise(normalise(poly_q(b, 1, x, y, z), vol.sy1), vol.sy1);
+    s.ux = unnormalise(normalise_axis(poly_q(b, 0, x, y, z), vol, 0), vol.sx1);
+    s.uy = unnormalise(normalise_axis(poly_q(b, 1, x, y, z), vol, 1), vol.sy1);
     axis_weights(s.ux, s.x0, s.wx0, s.wx1);
     axis_weights(s.uy, s.y0, s.wy0, s.wy1);
     if (HASZ) {
-        s.uz = unnormalise(normalise(poly_q(b, 2, x, y, z), vol.sz1), vol.sz1);
+        s.uz = unnormalise(normalise_axis(poly_q(b, 2, x, y, z), vol, 2), vol.sz1);
         axis_weights(s.uz, s.z0, s.wz0, s.wz1);
     } else {
         s.uz = 0.0f, s.z0 = 0, s.wz0 = 1.0f, s.wz1 = 0.0f;

@@ -37,9 +37,9 @@ __global__ __launch_bounds__(256) void image_iwarp_kernel(const float *__restric
                 voxel_xyz(v, vol, x, yy, z);
                 const float xf = (float)x, yf = (float)yy, zf = (float)z;
                 // ((n + 1) / 2) * sz[d], fp32 like the reference (flow_ is a float32 tensor there)
-                sx[i] = __fmul_rn(__fmul_rn(__fadd_rn(normalise(poly_q(bt, 0, xf, yf, zf), vol.sx1), 1.0f), 0.5f), (float)vol.X);
-                sy[i] = __fmul_rn(__fmul_rn(__fadd_rn(normalise(poly_q(bt, 1, xf, yf, zf), vol.sy1), 1.0f), 0.5f), (float)vol.Y);
-                sz[i] = vol.Z > 1 ? __fmul_rn(__fmul_rn(__fadd_rn(normalise(poly_q(bt, 2, xf, yf, zf), vol.sz1), 1.0f), 0.5f), (float)vol.Z)
+                sx[i] = __fmul_rn(__fmul_rn(__fadd_rn(normalise_axis(poly_q(bt, 0, xf, yf, zf), vol, 0), 1.0f), 0.5f), (float)vol.X);
+                sy[i] = __fmul_rn(__fmul_rn(__fadd_rn(normalise_axis(poly_q(bt, 1, xf, yf, zf), vol, 1), 1.0f), 0.5f), (float)vol.Y);
+                sz[i] = vol.Z > 1 ? __fmul_rn(__fmul_rn(__fadd_rn(normalise_axis(poly_q(bt, 2, xf, yf, zf), vol, 2), 1.0f), 0.5f), (float)vol.Z)
                                   : 0.0f;
             }
         }
