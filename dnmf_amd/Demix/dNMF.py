@@ -271,6 +271,7 @@ class DeformableNMF:
         self._ws_k2 = None
         self._ws_k3 = None
         self._S_bufs = None
+        self._gram_nbr = None   # (K,NN) columns of the last Gram matrices that can be non-zero, when K3n made them
         # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
         # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
         self.fused_motion = True
@@ -373,7 +374,7 @@ class DeformableNMF:
             T_loc = frames.shape[0]
             G, r = self._gram_rhs(frames, order)
             Csel = self.C.to(device, torch.float32)[:, order.long()].contiguous()
-            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c, group=self.group)
+            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c, group=self.group, nbr=self._gram_nbr)
             C = self.C.to(device, torch.float32).clone()
             C[:, order.long()] = Cnew
             self.C = C
@@ -398,9 +399,13 @@ class DeformableNMF:
     def _gram_rhs(self, frames, order):
         """Per-frame Gram matrices and right-hand sides under the current warp, summed over the channels."""
         G = r = None
-        for fp, cols in self._channels():
+        chans = self._channels()
+        self._gram_nbr = None
+        for fp, cols in chans:
             Gc, rc = self._gram_rhs_one(fp, frames if cols is None else frames[:, cols], order)
             G, r = (Gc, rc) if G is None else (G.add_(Gc), r.add_(rc))
+        if len(chans) > 1:
+            self._gram_nbr = None   # the channels' patterns may differ
         return G, r
 
     def _channels(self):
@@ -416,6 +421,7 @@ class DeformableNMF:
             if ly["nslot"] <= ops.LISTS_MAX_SLOTS and (self.gram_kernel == 'lists' or ly["boxfrac"] < LISTS_BOXFRAC_LIMIT):
                 G, r, self._ws_k3 = ops.warp_gram_rhs_lists(ly, fp.K, fp.sz_list, fp.beta.detach(), order, frames,
                                                             workspace=self._ws_k3)
+                self._gram_nbr = ly["nbr"]   # the pattern of this G, for K4
                 return G, r
             if self.gram_kernel == 'lists':
                 raise ValueError(f"gram_kernel='lists': the pattern of G has {ly['nslot']} slots > "
@@ -651,7 +657,7 @@ class MultiChannelDNMF(DeformableNMF):
         raise NotImplementedError("MultiChannelDNMF.spatial_step")
 
 
-def _mu_temporal(G, r, C, gamma, iters, group=None):
+def _mu_temporal(G, r, C, gamma, iters, group=None, nbr=None):
     """``iters`` multiplicative updates on (T,K,K) / (T,K) Gram data.
 
     ``C`` fp32 (K,T): the state update_footprints starts from (the reference's ``self.C``); without the
@@ -661,7 +667,7 @@ def _mu_temporal(G, r, C, gamma, iters, group=None):
     every round first exchanges the boundary columns (one all-gather of 2K doubles) so that the first / last frame
     of a shard sees its true neighbour instead of the replicated edge.  Returns a tensor of C's dtype."""
     if C.dtype == torch.float32 and (gamma is None or gamma == 0):
-        return ops.mu_temporal(G, r, C.contiguous().clone(), iters)
+        return ops.mu_temporal(G, r, C.contiguous().clone(), iters, nbr=nbr)
     a = C.double().contiguous().clone()
     b = torch.empty_like(a)
     sharded = group is not None and gamma is not None and gamma != 0 and torch.distributed.get_world_size(group) > 1

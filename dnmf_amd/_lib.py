@@ -38,6 +38,7 @@ SIGNATURES = {
     "dnmf_warp_gram_rhs_sparse_lt": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp,
                                           _sz, _vp, _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "dnmf_mu_temporal_nbr": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
     "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),

@@ -7,50 +7,63 @@
 //   j zero-gradient steps, one step with its gradient (evaluated at the coasted beta), n-1-j zero-gradient steps.
 // Columns are independent, so the epoch is: phase 0 (coast j steps) -> K2 for all frames -> phase 1 (the
 // gradient step and the remaining coasting).  Arithmetic follows torch's Adam (non-amsgrad, no weight
-// decay): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*exp_avg_sq + (1-b2) g^2; bias corrections in double,
+// decay): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*exp_avg_sq + (1-b2) g^2; bias corrections 1 - b^step in double,
 // applied as fp32 scalars; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * (m/denom).
 #include "common.hpp"
 
 namespace dnmf {
 
-__device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, double pow1, double pow2, double lr,
+// One step with the two step-dependent scalars already formed: step_size = -(lr / (1 - b1^step)) and
+// bc2_sqrt = sqrt(1 - b2^step), both evaluated in double and rounded to fp32 as torch does.
+__device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, float step_size, float bc2_sqrt,
                                          float b2f, float omb1, float omb2, float epsf) {
     m = m + omb1 * (g - m);                    // lerp_(grad, 1 - beta1)
     v = b2f * v + omb2 * (g * g);              // mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const double bc1 = 1.0 - pow1, bc2 = 1.0 - pow2;
-    const float step_size = (float)(-(lr / bc1));
-    const float bc2_sqrt = (float)sqrt(bc2);
     const float denom = sqrtf(v) / bc2_sqrt + epsf;
     p = p + step_size * (m / denom);           // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+constexpr int ADAM_CHUNK = 2048;  // steps whose scalars are tabulated in LDS at a time
+
 // One thread per (coefficient e, frame t).  phase 0: steps step0+1 .. step0+j_t with zero gradient.
 // phase 1: step step0+j_t+1 with grad, then zero-gradient steps up to step0+nsteps.  frame_step[t] < 0: the
 // frame is in no mini-batch of this epoch -> it coasts through all nsteps (done in phase 1).
+// The step-dependent scalars are the same for every column, so a block tabulates them once per chunk of steps
+// (double-precision pow / divide / sqrt, a few per thread) instead of every thread re-deriving them in every step.
 __global__ __launch_bounds__(256) void adam_epoch_kernel(float *__restrict__ beta, const float *__restrict__ grad,
                                                          float *__restrict__ m_, float *__restrict__ v_, int T,
                                                          long step0, const int *__restrict__ frame_step, int nsteps,
                                                          double lr, double b1, double b2, double eps, int phase) {
+    __shared__ float s_step[ADAM_CHUNK], s_bc2[ADAM_CHUNK];
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 30L * T) return;
-    const int t = (int)(i % T);
-    const int j = frame_step[t];
-    float p = beta[i], m = m_[i], v = v_[i];
+    const bool live = i < 30L * T;
+    const int j = live ? frame_step[(int)(i % T)] : 0;
+    float p = 0.0f, m = 0.0f, v = 0.0f;
+    if (live) p = beta[i], m = m_[i], v = v_[i];
     const float b2f = (float)b2, omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2), epsf = (float)eps;
-    int first, last;  // 1-based step numbers inside the epoch
-    if (phase == 0) {
-        first = 1, last = j < 0 ? 0 : j;
-    } else {
-        first = j < 0 ? 1 : j + 1, last = nsteps;
+    int first = 1, last = 0;  // 1-based step numbers inside the epoch
+    if (live) {
+        if (phase == 0)
+            first = 1, last = j < 0 ? 0 : j;
+        else
+            first = j < 0 ? 1 : j + 1, last = nsteps;
     }
-    if (first > last) return;
-    double pow1 = pow(b1, (double)(step0 + first)), pow2 = pow(b2, (double)(step0 + first));
-    for (int s = first; s <= last; ++s) {
-        const float g = (phase == 1 && s == j + 1 && j >= 0) ? grad[i] : 0.0f;
-        adam_one(p, m, v, g, pow1, pow2, lr, b2f, omb1, omb2, epsf);
-        pow1 *= b1, pow2 *= b2;
+    const float gval = (live && phase == 1 && j >= 0) ? grad[i] : 0.0f;
+    for (int c0 = 1; c0 <= nsteps; c0 += ADAM_CHUNK) {
+        const int c1 = min(c0 + ADAM_CHUNK - 1, nsteps);
+        __syncthreads();
+        for (int s = c0 + (int)threadIdx.x; s <= c1; s += blockDim.x) {
+            const double st = (double)(step0 + s);
+            s_step[s - c0] = (float)(-(lr / (1.0 - pow(b1, st))));
+            s_bc2[s - c0] = (float)sqrt(1.0 - pow(b2, st));
+        }
+        __syncthreads();
+        for (int s = max(first, c0); s <= min(last, c1); ++s) {
+            const float g = (phase == 1 && s == j + 1) ? gval : 0.0f;
+            adam_one(p, m, v, g, s_step[s - c0], s_bc2[s - c0], b2f, omb1, omb2, epsf);
+        }
     }
-    beta[i] = p, m_[i] = m, v_[i] = v;
+    if (live && first <= last) beta[i] = p, m_[i] = m, v_[i] = v;
 }
 
 }  // namespace dnmf

@@ -42,6 +42,40 @@ __global__ __launch_bounds__(256) void mu_temporal_kernel(const float *__restric
     if (live) C[(long)k * ldc + t] = (float)c;
 }
 
+// The same rounds when G has a known pattern (K3n: footprints whose boxes never meet have G = 0 for every warp).
+// nbr (K,NN): for row k the columns that can be non-zero, ascending, padded with columns outside the pattern.  The
+// dense kernel adds the terms in ascending column order and a term with G = 0 adds an exact zero, so the result is
+// bit-identical to mu_temporal_kernel's; only the work shrinks from K to NN terms per row and round.
+template <int NN>
+__global__ __launch_bounds__(256) void mu_temporal_nbr_kernel(const float *__restrict__ G, const float *__restrict__ r,
+                                                              float *__restrict__ C, long ldc, int K, int iters,
+                                                              const int *__restrict__ nbr) {
+    __shared__ double cs[256];
+    const int t = blockIdx.x;
+    const int k = threadIdx.x;
+    const float *Gt = G + (long)t * K * K;
+    const bool live = k < K;
+    double g[NN];
+    int li[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        li[j] = live ? nbr[k * NN + j] : 0;
+        g[j] = live ? (double)Gt[(long)li[j] * K + k] : 0.0;
+    }
+    const double rk = live ? (double)r[(long)t * K + k] : 0.0;
+    double c = live ? (double)C[(long)k * ldc + t] : 0.0;
+    for (int it = 0; it < iters; ++it) {
+        cs[k] = c;
+        __syncthreads();
+        double dot = 0.0;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) dot = fma(g[j], cs[li[j]], dot);
+        c = (c * rk) / (dot + 1e-32);
+        __syncthreads();
+    }
+    if (live) C[(long)k * ldc + t] = (float)c;
+}
+
 // one round with the temporal-smoothness term on an fp64 state (Jacobi: all of Cin is the old iterate)
 __global__ __launch_bounds__(256) void mu_temporal_step_kernel(const float *__restrict__ G, const float *__restrict__ r,
                                                                const double *__restrict__ Cin, double *__restrict__ Cout,
@@ -89,6 +123,26 @@ int dnmf_mu_temporal(const float *G, const float *r, float *C, long ldc, int K, 
     else
         hipLaunchKernelGGL(mu_temporal_kernel<0>, grid, dim3(256), 0, st, G, r, C, ldc, K, iters);
     return check_launch("dnmf_mu_temporal");
+}
+
+int dnmf_mu_temporal_nbr(const float *G, const float *r, float *C, long ldc, int K, int T, int iters, const int *nbr,
+                         int NN, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(G && r && C && nbr, DNMF_E_NULL, "dnmf_mu_temporal_nbr: NULL buffer");
+    DNMF_REQUIRE(K > 0 && T > 0 && ldc >= T && iters >= 0, DNMF_E_SHAPE, "dnmf_mu_temporal_nbr: K=%d T=%d ldc=%ld iters=%d",
+                 K, T, ldc, iters);
+    DNMF_REQUIRE(K <= 256 && (NN == 8 || NN == 16 || NN == 32), DNMF_E_UNSUPPORTED,
+                 "dnmf_mu_temporal_nbr: K=%d (<= 256), NN=%d (8, 16 or 32)", K, NN);
+    if (iters == 0) return DNMF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)T), block(K <= 64 ? 64 : (K <= 128 ? 128 : 256));
+    if (NN == 8)
+        hipLaunchKernelGGL(mu_temporal_nbr_kernel<8>, grid, block, 0, st, G, r, C, ldc, K, iters, nbr);
+    else if (NN == 16)
+        hipLaunchKernelGGL(mu_temporal_nbr_kernel<16>, grid, block, 0, st, G, r, C, ldc, K, iters, nbr);
+    else
+        hipLaunchKernelGGL(mu_temporal_nbr_kernel<32>, grid, block, 0, st, G, r, C, ldc, K, iters, nbr);
+    return check_launch("dnmf_mu_temporal_nbr");
 }
 
 int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K, int T,

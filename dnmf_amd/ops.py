@@ -175,12 +175,17 @@ def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_strid
     return G, r, workspace
 
 
-def mu_temporal(G, r, C, iters: int):
-    """K4 without the neighbour term: C (K,T) fp32 updated in place."""
+def mu_temporal(G, r, C, iters: int, nbr=None):
+    """K4 without the neighbour term: C (K,T) fp32 updated in place.  ``nbr`` (K,NN) int32: the columns of G that
+    can be non-zero per row (``pack_footprints_lists``) -- same result, NN instead of K terms per row."""
     _f32(G, "G"), _f32(r, "r")
     if not (C.is_cuda and C.dtype == torch.float32 and C.stride(1) == 1):
         raise ValueError("mu_temporal: C must be float32 CUDA with unit inner stride")
     T, K = r.shape
+    if nbr is not None:
+        _lib.check(_lib.load().dnmf_mu_temporal_nbr(G.data_ptr(), r.data_ptr(), C.data_ptr(), C.stride(0), K, T, int(iters),
+                                                    nbr.data_ptr(), nbr.shape[1], _stream()), "dnmf_mu_temporal_nbr")
+        return C
     _lib.check(_lib.load().dnmf_mu_temporal(G.data_ptr(), r.data_ptr(), C.data_ptr(), C.stride(0), K, T, int(iters),
                                             _stream()), "dnmf_mu_temporal")
     return C
@@ -282,7 +287,15 @@ def pack_footprints_lists(A, sz):
                "dnmf_pack_footprints_lists")
     bb = bbox.cpu().long()
     ext = (bb[:, 1::2] - bb[:, 0::2] + 1).clamp_min(0)
-    return {"At": At, "bbox": bbox, "pair_slot": pair_slot, "nslot": int(nslot.item()),
+    ns = int(nslot.item())
+    # per row of G the columns inside the pattern, ascending, padded with columns outside it (for K4)
+    pattern = pair_slot != ns - 1
+    widest = int(pattern.sum(1).max().item())
+    NN = next((n for n in (8, 16, 32) if widest <= n <= K), None)
+    nbr = None
+    if NN is not None:
+        nbr = torch.argsort((~pattern).to(torch.uint8), dim=1, stable=True)[:, :NN].to(torch.int32).contiguous()
+    return {"At": At, "bbox": bbox, "pair_slot": pair_slot, "nslot": ns, "nbr": nbr,
             "boxfrac": float(ext.prod(1).sum()) / (X * Y * Z)}
 
 

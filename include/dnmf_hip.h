@@ -184,6 +184,11 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
  *   T-shard) are given. */
 int dnmf_mu_temporal(const float *G, const float *r, float *C, long ldc, int K, int T, int iters,
                      dnmf_stream_t stream);
+/* dnmf_mu_temporal when G has a known pattern (the static pattern of K3n): nbr (K,NN) int32 lists for every row the
+ * columns that can be non-zero in ascending order, padded with columns that cannot; NN in {8,16,32}.  Bit-identical
+ * results (the skipped terms are exact zeros), NN instead of K terms per row and round. */
+int dnmf_mu_temporal_nbr(const float *G, const float *r, float *C, long ldc, int K, int T, int iters, const int *nbr,
+                         int NN, dnmf_stream_t stream);
 int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K,
                           int T, double gamma, const double *c_left, const double *c_right,
                           dnmf_stream_t stream);

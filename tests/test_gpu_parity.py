@@ -542,6 +542,13 @@ def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma):
     assert torch.equal(Gn == 0, Gd == 0) or float(Gd[(Gn == 0) != (Gd == 0)].abs().max()) < 1e-30
     G2, r2, _ = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames, workspace=ws)
     assert torch.equal(G2, Gn) and torch.equal(r2, rn)
+    # K4 restricted to the pattern of G gives bit-identical traces
+    if ly["nbr"] is not None:
+        C0 = torch.rand(K, T, device="cuda")
+        pat = (ly["pair_slot"] != ly["nslot"] - 1)
+        assert bool((Gn[:, ~pat] == 0).all())
+        assert all(bool(pat[k, ly["nbr"][k].long()].sum() == pat[k].sum()) for k in range(K))
+        assert torch.equal(ops.mu_temporal(Gn, rn, C0.clone(), 9, nbr=ly["nbr"]), ops.mu_temporal(Gn, rn, C0.clone(), 9))
     # a subset of frames in another order, through the model switch
     dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
     dn.fp, dn.gram_kernel = fp, 'lists'
