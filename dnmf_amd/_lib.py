@@ -21,7 +21,7 @@ SIGNATURES = {
     "dnmf_pack_footprints": (_i, [_vp, _l, _i, _vp, _i, _vp]),
     "dnmf_warp_gather": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "dnmf_recon_image": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
-    "dnmf_warp_recon_grad_workspace": (_sz, [_l, _i]),
+    "dnmf_warp_recon_grad_workspace": (_sz, [_i, _i, _i, _i]),
     "dnmf_warp_recon_grad": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _sz, _vp]),
     "dnmf_warp_gram_rhs_workspace": (_sz, [_l, _i, _i]),

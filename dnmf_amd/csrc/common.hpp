@@ -83,10 +83,14 @@ __device__ __forceinline__ float normalise_fast(float q, float sm1, float rcp) {
     return __fsub_rn(__fmaf_rn(e, rcp, q0), 1.0f);
 }
 
-// n along axis d of the volume (0, 1, 2), by the shortcut when the volume allows it (wave-uniform choice)
+// n along axis d of the volume (0, 1, 2), by the shortcut when the volume allows it.  FAST = 1 / 0: the caller has
+// already branched on vol.fastdiv (kernel variants); -1: wave-uniform choice here.
+template <int FAST = -1>
 __device__ __forceinline__ float normalise_axis(float q, const Volume &vol, int d) {
     const float sm1 = d == 0 ? vol.sx1 : (d == 1 ? vol.sy1 : vol.sz1);
     const float rcp = d == 0 ? vol.rx1 : (d == 1 ? vol.ry1 : vol.rz1);
+    if (FAST == 1) return normalise_fast(q, sm1, rcp);
+    if (FAST == 0) return normalise(q, sm1);
     return vol.fastdiv ? normalise_fast(q, sm1, rcp) : normalise(q, sm1);
 }
 
@@ -108,16 +112,16 @@ __device__ __forceinline__ void axis_weights(float u, int &i0, float &w0, float 
 
 // Full sample for voxel (x,y,z) under beta `b`.  Z == 1: z pinned to 0 (weight 1 on slice 0).
 // HASZ = false is the Z == 1 specialisation (z == 0 folds the z terms of the polynomial away).
-template <bool HASZ>
+template <bool HASZ, int FAST = -1>
 __device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vol, int xi, int yi, int zi) {
     const float x = (float)xi, y = (float)yi, z = HASZ ? (float)zi : 0.0f;
     Sample s;
-    s.ux = unnormalise(normalise_axis(poly_q(b, 0, x, y, z), vol, 0), vol.sx1);
-    s.uy = unnormalise(normalise_axis(poly_q(b, 1, x, y, z), vol, 1), vol.sy1);
+    s.ux = unnormalise(normalise_axis<FAST>(poly_q(b, 0, x, y, z), vol, 0), vol.sx1);
+    s.uy = unnormalise(normalise_axis<FAST>(poly_q(b, 1, x, y, z), vol, 1), vol.sy1);
     axis_weights(s.ux, s.x0, s.wx0, s.wx1);
     axis_weights(s.uy, s.y0, s.wy0, s.wy1);
     if (HASZ) {
-        s.uz = unnormalise(normalise_axis(poly_q(b, 2, x, y, z), vol, 2), vol.sz1);
+        s.uz = unnormalise(normalise_axis<FAST>(poly_q(b, 2, x, y, z), vol, 2), vol.sz1);
         axis_weights(s.uz, s.z0, s.wz0, s.wz1);
     } else {
         s.uz = 0.0f, s.z0 = 0, s.wz0 = 1.0f, s.wz1 = 0.0f;

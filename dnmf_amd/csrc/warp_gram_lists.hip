@@ -89,7 +89,7 @@ __device__ __forceinline__ int wave_minmax_last(int v) {
     return v;
 }
 
-template <int NTAP, int NW>
+template <int NTAP, int NW, int FAST>
 __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     extern __shared__ float s_tab[];
     const int lane = threadIdx.x & 63;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
             for (int c = 0; c < NTAP; ++c) off[v][c] = 0u, w[v][c] = 0.0f;
             yv[v] = 0.0f;
             if (x < vol.X && y < vol.Y && z < vol.Z) {
-                const Sample sm = make_sample_t<(NTAP == 8)>(bt, vol, x, y, z);
+                const Sample sm = make_sample_t<(NTAP == 8), FAST>(bt, vol, x, y, z);
                 unsigned vox[NTAP];
                 make_taps<NTAP>(sm, vol, w[v], vox);
 #pragma unroll
@@ -415,7 +415,10 @@ static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len)
 
 template <int NTAP, int NW>
 static void launch_lists_t(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW>), dim3(nwg), dim3(256), lds, st, p);
+    if (p.vol.fastdiv)
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1>), dim3(nwg), dim3(256), lds, st, p);
+    else
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 0>), dim3(nwg), dim3(256), lds, st, p);
 }
 
 }  // namespace dnmf

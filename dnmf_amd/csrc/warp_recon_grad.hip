@@ -12,8 +12,8 @@
 
 namespace dnmf {
 
-constexpr int K2_VPT = 16;            // voxels per thread
-constexpr int K2_VPB = 256 * K2_VPT;  // voxels per block
+constexpr int K2_ROWS = 16;           // voxels per lane: consecutive x
+constexpr int K2_COLS = 256;          // positions of the (y,z) plane per block: 64 lanes x 4 waves
 constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -22,9 +22,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Work layout: a block owns 16 x-rows by 256 consecutive positions of the (y,z) plane (lane = position, so the frame
+// and the reconstruction image are read in 256-byte runs and the taps of neighbouring lanes share cache lines); a
+// thread walks down its 16 rows.  x, y, z follow from the block and lane indices by additions.
+//
 // HASZ = false is the Z == 1 specialisation: two coordinates, four taps, and only the six basis terms without z
 // (the other 18 gradient sums are identically zero and are written as such).
-template <bool HASZ>
+template <bool HASZ, int FAST>
 __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
                                                               const int *__restrict__ s_ids,
                                                               const float *__restrict__ frames, long ldf,
@@ -32,13 +36,14 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
                                                               const float *__restrict__ gout, Volume vol,
                                                               const float *__restrict__ beta, int T,
                                                               const int *__restrict__ times,
-                                                              float *__restrict__ recon, float *__restrict__ partial) {
+                                                              float *__restrict__ recon, float *__restrict__ partial,
+                                                              int nub) {
     constexpr int ND = HASZ ? 3 : 2;                 // warped coordinates that exist
     constexpr int NA = HASZ ? 10 : 6;                // basis terms that are not identically zero
     constexpr int BASIS_ID[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};  // z-free terms first
     const int b = blockIdx.y;
-    const float *s = S + (long)(s_ids ? s_ids[b] : b) * lds;
-    const float *y = frames ? frames + (long)(frame_ids ? frame_ids[b] : b) * ldf : nullptr;
+    const char *__restrict__ s = reinterpret_cast<const char *>(S + (long)(s_ids ? s_ids[b] : b) * lds);
+    const float *__restrict__ y = frames ? frames + (long)(frame_ids ? frame_ids[b] : b) * ldf : nullptr;
     float bt[30];
     load_beta(beta, T, times[b], bt);
 
@@ -49,61 +54,75 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
         for (int d = 0; d < ND; ++d) acc[a][d] = 0.0f;
     float sq = 0.0f;
     const int YZ = vol.Y * vol.Z;
+    const int bu = blockIdx.x % nub, bx = blockIdx.x / nub;
+    const int u = bu * K2_COLS + threadIdx.x;          // position in the (y,z) plane
+    const int yy = HASZ ? div_small(u, vol.Z, vol.rcp_z) : u;
+    const int z = HASZ ? u - yy * vol.Z : 0;
+    const float yf = (float)yy, zf = (float)z;
 
-    for (int i = 0; i < K2_VPT; ++i) {
-        const long p = (long)blockIdx.x * K2_VPB + i * 256 + threadIdx.x;
-        if (p >= vol.P) break;
-        int x, yy, z;
-        voxel_xyz(p, vol, x, yy, z);
-        const Sample sm = make_sample_t<HASZ>(bt, vol, x, yy, z);
-        // Branch-free gather: corner indices clamped into the volume, per-axis weights (w) and validity flags (v)
-        // zeroed for corners outside it.  A corner's value weight is wx*wy*wz and its x-derivative weight
-        // +-vx*wy*wz (ATen's grid_sampler backward skips out-of-bounds corners), so everything factorises per axis.
-        const float wx[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
-        const float wy[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
-        const float vx[2] = {in_range(sm.x0, vol.X) ? 1.0f : 0.0f, in_range(sm.x0 + 1, vol.X) ? 1.0f : 0.0f};
-        const float vy[2] = {in_range(sm.y0, vol.Y) ? 1.0f : 0.0f, in_range(sm.y0 + 1, vol.Y) ? 1.0f : 0.0f};
-        const int xo[2] = {min(max(sm.x0, 0), vol.X - 1) * YZ, min(max(sm.x0 + 1, 0), vol.X - 1) * YZ};
-        const int yo[2] = {min(max(sm.y0, 0), vol.Y - 1) * vol.Z, min(max(sm.y0 + 1, 0), vol.Y - 1) * vol.Z};
-        float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
+    if (u < YZ) {
+        const int nrow = min(K2_ROWS, vol.X - bx * K2_ROWS);
+#pragma unroll 2
+        for (int i = 0; i < nrow; ++i) {
+            const int x = bx * K2_ROWS + i;
+            const long p = (long)x * YZ + u;
+            const Sample sm = make_sample_t<HASZ, FAST>(bt, vol, x, yy, z);
+            // Branch-free gather: corner indices clamped into the volume, per-axis weights (w) and validity flags (v)
+            // zeroed for corners outside it.  A corner's value weight is wx*wy*wz and its x-derivative weight
+            // +-vx*wy*wz (ATen's grid_sampler backward skips out-of-bounds corners), so everything factorises per
+            // axis.
+            const float wx[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
+            const float wy[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
+            const float vx[2] = {in_range(sm.x0, vol.X) ? 1.0f : 0.0f, in_range(sm.x0 + 1, vol.X) ? 1.0f : 0.0f};
+            const float vy[2] = {in_range(sm.y0, vol.Y) ? 1.0f : 0.0f, in_range(sm.y0 + 1, vol.Y) ? 1.0f : 0.0f};
+            const unsigned xo[2] = {(unsigned)(min(max(sm.x0, 0), vol.X - 1) * YZ),
+                                    (unsigned)(min(max(sm.x0 + 1, 0), vol.X - 1) * YZ)};
+            const unsigned yo[2] = {(unsigned)(min(max(sm.y0, 0), vol.Y - 1) * vol.Z),
+                                    (unsigned)(min(max(sm.y0 + 1, 0), vol.Y - 1) * vol.Z)};
+            float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-            const int zo = HASZ ? min(max(sm.z0 + dz, 0), vol.Z - 1) : 0;
-            float sv[2][2];  // [dy][dx]
+            for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
+                const unsigned zo = HASZ ? (unsigned)min(max(sm.z0 + dz, 0), vol.Z - 1) : 0u;
+                float sv[2][2];  // [dy][dx]
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
+                for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) sv[dy][dx] = s[xo[dx] + yo[dy] + zo];
-            const float a0 = fmaf(wx[1], sv[0][1], wx[0] * sv[0][0]);  // x-interpolated rows y0, y1
-            const float a1 = fmaf(wx[1], sv[1][1], wx[0] * sv[1][0]);
-            const float d0 = fmaf(vx[1], sv[0][1], -(vx[0] * sv[0][0]));  // x-differences of the rows
-            const float d1 = fmaf(vx[1], sv[1][1], -(vx[0] * sv[1][0]));
-            const float r2 = fmaf(wy[1], a1, wy[0] * a0);       // value of this z-slice
-            const float gx2 = fmaf(wy[1], d1, wy[0] * d0);
-            const float gy2 = fmaf(vy[1], a1, -(vy[0] * a0));
-            if (HASZ) {
-                const bool zin = in_range(sm.z0 + dz, vol.Z);
-                const float wz = zin ? (dz ? sm.wz1 : sm.wz0) : 0.0f;
-                const float vz = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
-                rec = fmaf(wz, r2, rec);
-                g[0] = fmaf(wz, gx2, g[0]);
-                g[1] = fmaf(wz, gy2, g[1]);
-                g[2] = fmaf(vz, r2, g[2]);
-            } else {
-                rec = r2, g[0] = gx2, g[1] = gy2;
+                    for (int dx = 0; dx < 2; ++dx) {
+                        unsigned o = (xo[dx] + yo[dy] + zo) * 4u;  // byte offset: (scalar base + 32-bit offset) loads
+                        asm("" : "+v"(o));
+                        sv[dy][dx] = *reinterpret_cast<const float *>(s + o);
+                    }
+                const float a0 = fmaf(wx[1], sv[0][1], wx[0] * sv[0][0]);  // x-interpolated rows y0, y1
+                const float a1 = fmaf(wx[1], sv[1][1], wx[0] * sv[1][0]);
+                const float d0 = fmaf(vx[1], sv[0][1], -(vx[0] * sv[0][0]));  // x-differences of the rows
+                const float d1 = fmaf(vx[1], sv[1][1], -(vx[0] * sv[1][0]));
+                const float r2 = fmaf(wy[1], a1, wy[0] * a0);       // value of this z-slice
+                const float gx2 = fmaf(wy[1], d1, wy[0] * d0);
+                const float gy2 = fmaf(vy[1], a1, -(vy[0] * a0));
+                if (HASZ) {
+                    const bool zin = in_range(sm.z0 + dz, vol.Z);
+                    const float wz = zin ? (dz ? sm.wz1 : sm.wz0) : 0.0f;
+                    const float vz = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
+                    rec = fmaf(wz, r2, rec);
+                    g[0] = fmaf(wz, gx2, g[0]);
+                    g[1] = fmaf(wz, gy2, g[1]);
+                    g[2] = fmaf(vz, r2, g[2]);
+                } else {
+                    rec = r2, g[0] = gx2, g[1] = gy2;
+                }
             }
-        }
-        if (recon) recon[(long)b * vol.P + p] = rec;
-        // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
-        const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
-        sq = fmaf(resid, resid, sq);
-        const float xf = (float)x, yf = (float)yy, zf = (float)z;
-        const float basis[10] = {1.0f, xf, yf, xf * xf, yf * yf, xf * yf, zf, zf * zf, xf * zf, yf * zf};
+            if (recon) recon[(long)b * vol.P + p] = rec;
+            // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
+            const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
+            sq = fmaf(resid, resid, sq);
+            const float xf = (float)x;
+            const float basis[10] = {1.0f, xf, yf, xf * xf, yf * yf, xf * yf, zf, zf * zf, xf * zf, yf * zf};
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const float gd = resid * g[d];
+            for (int d = 0; d < ND; ++d) {
+                const float gd = resid * g[d];
 #pragma unroll
-            for (int a = 0; a < NA; ++a) acc[a][d] = fmaf(basis[a], gd, acc[a][d]);
+                for (int a = 0; a < NA; ++a) acc[a][d] = fmaf(basis[a], gd, acc[a][d]);
+            }
         }
     }
 
@@ -195,10 +214,15 @@ __global__ __launch_bounds__(64) void sum_loss_kernel(const float *__restrict__ 
 
 extern "C" {
 
-size_t dnmf_warp_recon_grad_workspace(long P, int B) {
-    if (P <= 0 || B <= 0) return 0;
-    const long nblk = (P + dnmf::K2_VPB - 1) / dnmf::K2_VPB;
-    return (size_t)B * nblk * dnmf::K2_NACC * sizeof(float) + (size_t)B * sizeof(float);
+static long k2_blocks(int X, int Y, int Z, int *nub_out) {
+    const long nub = ((long)Y * Z + dnmf::K2_COLS - 1) / dnmf::K2_COLS;
+    if (nub_out) *nub_out = (int)nub;
+    return nub * ((X + dnmf::K2_ROWS - 1) / dnmf::K2_ROWS);
+}
+
+size_t dnmf_warp_recon_grad_workspace(int X, int Y, int Z, int B) {
+    if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
+    return (size_t)B * k2_blocks(X, Y, Z, nullptr) * dnmf::K2_NACC * sizeof(float) + (size_t)B * sizeof(float);
 }
 
 int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
@@ -213,19 +237,28 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
     const Volume vol = make_volume(X, Y, Z);
     DNMF_REQUIRE(lds >= vol.P && (!frames || ldf >= vol.P), DNMF_E_SHAPE, "dnmf_warp_recon_grad: lds=%ld ldf=%ld < P=%ld", lds,
                  ldf, vol.P);
-    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(vol.P, B), DNMF_E_WORKSPACE,
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(X, Y, Z, B), DNMF_E_WORKSPACE,
                  "dnmf_warp_recon_grad: workspace %zu < %zu bytes", workspace_bytes,
-                 dnmf_warp_recon_grad_workspace(vol.P, B));
-    const int nblk = (int)((vol.P + K2_VPB - 1) / K2_VPB);
+                 dnmf_warp_recon_grad_workspace(X, Y, Z, B));
+    DNMF_REQUIRE(vol.P < (1L << 30), DNMF_E_UNSUPPORTED, "dnmf_warp_recon_grad: P=%ld does not fit 32-bit byte offsets",
+                 vol.P);
+    int nub = 0;
+    const long nblk_l = k2_blocks(X, Y, Z, &nub);
+    DNMF_REQUIRE(nblk_l < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_warp_recon_grad: %ld blocks per frame", nblk_l);
+    const int nblk = (int)nblk_l;
     float *partial = static_cast<float *>(workspace);
     float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
     hipStream_t st = (hipStream_t)stream;
-    if (Z > 1)
-        hipLaunchKernelGGL(warp_recon_grad_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds,
-                           s_ids, frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
-    else
-        hipLaunchKernelGGL(warp_recon_grad_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, S, lds,
-                           s_ids, frames, ldf, frame_ids, gout, vol, beta, T, times, recon, partial);
+    const dim3 grid((unsigned)nblk, (unsigned)B);
+#define DNMF_K2_LAUNCH(HZ, FD)                                                                                            \
+    hipLaunchKernelGGL((warp_recon_grad_kernel<HZ, FD>), grid, dim3(256), 0, st, S, lds, s_ids, frames, ldf, frame_ids, \
+                       gout, vol, beta, T, times, recon, partial, nub)
+    if (Z > 1) {
+        if (vol.fastdiv) DNMF_K2_LAUNCH(true, 1); else DNMF_K2_LAUNCH(true, 0);
+    } else {
+        if (vol.fastdiv) DNMF_K2_LAUNCH(false, 1); else DNMF_K2_LAUNCH(false, 0);
+    }
+#undef DNMF_K2_LAUNCH
     if (norm_frames <= 0) norm_frames = B;
     const float grad_scale = gout ? 1.0f : 2.0f / ((float)norm_frames * (float)vol.P);
     hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T,

@@ -124,7 +124,7 @@ def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gou
     tt = _i32(times, dev)
     B = tt.numel()
     lib = _lib.load()
-    need = lib.dnmf_warp_recon_grad_workspace(P, B)
+    need = lib.dnmf_warp_recon_grad_workspace(X, Y, Z, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     recon = torch.empty((B, P), dtype=torch.float32, device=dev) if want_recon else None

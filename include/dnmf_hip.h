@@ -83,8 +83,8 @@ int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, lo
  *           mini-batches of norm_frames frames each
  *   loss    (1) sum over b of frame_loss;  frame_loss (B) per-frame sum of squares / (norm_frames*P) or NULL
  *   reg     (B) or NULL
- *   workspace: dnmf_warp_recon_grad_workspace(P,B) bytes */
-size_t dnmf_warp_recon_grad_workspace(long P, int B);
+ *   workspace: dnmf_warp_recon_grad_workspace(X,Y,Z,B) bytes */
+size_t dnmf_warp_recon_grad_workspace(int X, int Y, int Z, int B);
 int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
                          const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta,
                          int T, const int *times, int B, int norm_frames, float *recon, float *grad, float *loss,
