@@ -64,6 +64,25 @@ __device__ __forceinline__ float poly_q(const float *b, int d, float x, float y,
     return q;
 }
 
+// The same chain for Z == 1 (z = 0): the four terms with z add an exact zero each (finite coefficients), so they are
+// left out; the remaining six keep their order.
+__device__ __forceinline__ float poly_q_xy(const float *b, int d, float x, float y) {
+    float q = b[0 + d];
+    q = fmaf(b[3 + d], x, q);
+    q = fmaf(b[6 + d], y, q);
+    q = fmaf(b[12 + d], __fmul_rn(x, x), q);
+    q = fmaf(b[15 + d], __fmul_rn(y, y), q);
+    q = fmaf(b[21 + d], __fmul_rn(x, y), q);
+    return q;
+}
+
+// clamp into [0, n-1] in one instruction (v_med3_i32)
+__device__ __forceinline__ int clamp_index(int i, int n) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(n - 1));
+    return r;
+}
+
 // n = 2q/(S-1) - 1 exactly as the reference evaluates it in fp32 (Demix/dNMF.py:55): IEEE multiply,
 // IEEE divide, IEEE subtract, no contraction.
 __device__ __forceinline__ float normalise(float q, float sm1) {
@@ -116,8 +135,8 @@ template <bool HASZ, int FAST = -1>
 __device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vol, int xi, int yi, int zi) {
     const float x = (float)xi, y = (float)yi, z = HASZ ? (float)zi : 0.0f;
     Sample s;
-    s.ux = unnormalise(normalise_axis<FAST>(poly_q(b, 0, x, y, z), vol, 0), vol.sx1);
-    s.uy = unnormalise(normalise_axis<FAST>(poly_q(b, 1, x, y, z), vol, 1), vol.sy1);
+    s.ux = unnormalise(normalise_axis<FAST>(HASZ ? poly_q(b, 0, x, y, z) : poly_q_xy(b, 0, x, y), vol, 0), vol.sx1);
+    s.uy = unnormalise(normalise_axis<FAST>(HASZ ? poly_q(b, 1, x, y, z) : poly_q_xy(b, 1, x, y), vol, 1), vol.sy1);
     axis_weights(s.ux, s.x0, s.wx0, s.wx1);
     axis_weights(s.uy, s.y0, s.wy0, s.wy1);
     if (HASZ) {
@@ -143,13 +162,13 @@ template <int NTAP>
 __device__ __forceinline__ void make_taps(const Sample &sm, const Volume &vol, float *w, unsigned *vox) {
     const float wxm[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
     const float wym[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
-    const int xc[2] = {min(max(sm.x0, 0), vol.X - 1), min(max(sm.x0 + 1, 0), vol.X - 1)};
-    const int yc[2] = {min(max(sm.y0, 0), vol.Y - 1), min(max(sm.y0 + 1, 0), vol.Y - 1)};
+    const int xc[2] = {clamp_index(sm.x0, vol.X), clamp_index(sm.x0 + 1, vol.X)};
+    const int yc[2] = {clamp_index(sm.y0, vol.Y), clamp_index(sm.y0 + 1, vol.Y)};
     float wzm[2] = {1.0f, 0.0f};
     int zc[2] = {0, 0};
     if (NTAP == 8) {
         wzm[0] = in_range(sm.z0, vol.Z) ? sm.wz0 : 0.0f, wzm[1] = in_range(sm.z0 + 1, vol.Z) ? sm.wz1 : 0.0f;
-        zc[0] = min(max(sm.z0, 0), vol.Z - 1), zc[1] = min(max(sm.z0 + 1, 0), vol.Z - 1);
+        zc[0] = clamp_index(sm.z0, vol.Z), zc[1] = clamp_index(sm.z0 + 1, vol.Z);
     }
 #pragma unroll
     for (int c = 0; c < NTAP; ++c) {

@@ -75,14 +75,13 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
             const float wy[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
             const float vx[2] = {in_range(sm.x0, vol.X) ? 1.0f : 0.0f, in_range(sm.x0 + 1, vol.X) ? 1.0f : 0.0f};
             const float vy[2] = {in_range(sm.y0, vol.Y) ? 1.0f : 0.0f, in_range(sm.y0 + 1, vol.Y) ? 1.0f : 0.0f};
-            const unsigned xo[2] = {(unsigned)(min(max(sm.x0, 0), vol.X - 1) * YZ),
-                                    (unsigned)(min(max(sm.x0 + 1, 0), vol.X - 1) * YZ)};
-            const unsigned yo[2] = {(unsigned)(min(max(sm.y0, 0), vol.Y - 1) * vol.Z),
-                                    (unsigned)(min(max(sm.y0 + 1, 0), vol.Y - 1) * vol.Z)};
+            const unsigned xo[2] = {(unsigned)(clamp_index(sm.x0, vol.X) * YZ), (unsigned)(clamp_index(sm.x0 + 1, vol.X) * YZ)};
+            const unsigned yo[2] = {(unsigned)(clamp_index(sm.y0, vol.Y) * vol.Z),
+                                    (unsigned)(clamp_index(sm.y0 + 1, vol.Y) * vol.Z)};
             float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-                const unsigned zo = HASZ ? (unsigned)min(max(sm.z0 + dz, 0), vol.Z - 1) : 0u;
+                const unsigned zo = HASZ ? (unsigned)clamp_index(sm.z0 + dz, vol.Z) : 0u;
                 float sv[2][2];  // [dy][dx]
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
