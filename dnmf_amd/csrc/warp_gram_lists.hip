@@ -31,7 +31,7 @@
 
 namespace dnmf {
 
-constexpr int LISTS_NG = 6;      // neurons evaluated together (register slots); longer lists are cut into groups
+constexpr int LISTS_NG = 4;      // neurons evaluated together (register slots); longer lists are cut into groups
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x (3800 + 256) words of LDS per workgroup
 
@@ -261,11 +261,9 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
                 case 1: within(integral_constant<int, 1>{}, kA, aA); break;
                 case 2: within(integral_constant<int, 2>{}, kA, aA); break;
                 case 3: within(integral_constant<int, 3>{}, kA, aA); break;
-                case 4: within(integral_constant<int, 4>{}, kA, aA); break;
-                case 5: within(integral_constant<int, 5>{}, kA, aA); break;
-                default: within(integral_constant<int, 6>{}, kA, aA); break;
+                default: within(integral_constant<int, 4>{}, kA, aA); break;
             }
-            static_assert(LISTS_NG == 6, "the dispatch above lists the group sizes");
+            static_assert(LISTS_NG == 4, "the dispatch above lists the group sizes");
             // pairs of this (then full) group with every later group
             for (int g2 = g1 + LISTS_NG; g2 < n; g2 += LISTS_NG) {
                 int kB[LISTS_NG];
