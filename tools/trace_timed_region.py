@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel average duration over the TIMED steps of a bench run, from a rocprofv3 --kernel-trace CSV.
 
-    python tools/trace_timed_region.py <..._kernel_trace.csv> <steps> [out.json]
+    python tools/trace_timed_region.py <..._kernel_trace.csv> <steps> <warmup> [out.json]
 
 `rocprofv3 --stats` averages over every dispatch of the process, including the warm-up steps, whose launches run
 30-70 % slower (first touch of freshly allocated buffers, clock ramp).  bench.py times the last <steps> sweeps only;
@@ -15,23 +15,16 @@ import sys
 
 
 def main():
-    path, steps = sys.argv[1], int(sys.argv[2])
+    path, steps, warmup = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     out = {}
     for name, rows in by.items():
-        if "dnmf::" not in name or len(rows) < steps:
-            continue
+        if "dnmf::" not in name or len(rows) % (steps + warmup):
+            continue  # not launched the same number of times in every sweep (set-up kernels, the extra dense launch)
         rows.sort()
-        per_step = len(rows) // steps if len(rows) % steps == 0 else None
-        if per_step is None:  # warm-up launches present: assume the same number per sweep
-            for cand in (1, 2, 3, 4):
-                if (len(rows) - cand * steps) % cand == 0 and len(rows) >= cand * steps:
-                    per_step = cand
-                    break
-        if per_step is None:
-            continue
+        per_step = len(rows) // (steps + warmup)
         last = [d for _, d in rows[-per_step * steps:]]
         short = name.split("(")[0].replace("void ", "")
         out[short] = {"launches_in_timed_region": len(last), "avg_ms": sum(last) / len(last) / 1e6,
@@ -39,8 +32,8 @@ def main():
                       "avg_ms_all_launches": sum(d for _, d in rows) / len(rows) / 1e6}
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["launches_in_timed_region"]):
         print(f"{k:60s} {v['launches_in_timed_region']:4d} x {v['avg_ms']:.4f} ms  (all {v['all_launches']} launches: {v['avg_ms_all_launches']:.4f})")
-    if len(sys.argv) > 3:
-        json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    if len(sys.argv) > 4:
+        json.dump(out, open(sys.argv[4], "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
