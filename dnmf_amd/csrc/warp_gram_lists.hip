@@ -33,6 +33,7 @@ namespace dnmf {
 
 constexpr int LISTS_NG = 4;      // neurons evaluated together (register slots); longer lists are cut into groups
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
+constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items per launch
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x (3800 + 256) words of LDS per workgroup
 
 struct ListParams {
@@ -403,7 +404,7 @@ static void lists_tile_shape(const Volume &vol, int &lgx, int &lgz, int &nty, in
 }
 
 static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len) {
-    long want = (16384 + B - 1) / B;  // aim for >= 16k wave-sized work items (four or more waves per SIMD)
+    long want = (LISTS_ITEMS + B - 1) / B;  // wave-sized work items: several rounds of four waves per SIMD
     if (want < 1) want = 1;
     if (want > 64) want = 64;
     if (want > ntiles) want = ntiles;
@@ -441,7 +442,7 @@ int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float
 
 size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int B) {
     if (nslot <= 0 || B <= 0) return 0;
-    long want = (16384 + B - 1) / B;
+    long want = (dnmf::LISTS_ITEMS + B - 1) / B;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
     return (size_t)B * (size_t)want * (size_t)nslot * sizeof(float);
