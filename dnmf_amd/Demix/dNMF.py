@@ -585,8 +585,9 @@ class DeformableNMF:
         n = plan.nsteps
         step0 = int(state['step'])
         args = (step0, plan.frame_step.to(device), n, g['lr'], g['betas'], g['eps'])
+        order = plan.order.to(device)
         with torch.no_grad():
-            ops.adam_epoch(beta, None, state['exp_avg'], state['exp_avg_sq'], *args, phase=0)
+            ops.adam_epoch(beta, None, state['exp_avg'], state['exp_avg_sq'], *args, phase=0, order=order)
             grad = torch.zeros_like(beta)
             outs = []
             for idx, nf in plan.groups:
@@ -595,7 +596,7 @@ class DeformableNMF:
                 idx = idx.to(device, torch.int32)
                 out = self._k2(S_all, None, loader.frames_2d(), idx, idx, grad, nf, self.verbose)
                 outs.append((idx, nf, out))
-            ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1)
+            ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1, order=order)
         state['step'] += n
         beta.grad = grad
         if self.verbose and outs:

@@ -225,15 +225,17 @@ def render_frames(positions, traces, sz, shape_std, t0=0, T=None, out=None):
     return out
 
 
-def adam_epoch(beta, grad, exp_avg, exp_avg_sq, step0, frame_step, nsteps, lr, betas, eps, phase):
-    """One phase of the per-column Adam epoch (see include/dnmf_hip.h); tensors updated in place."""
+def adam_epoch(beta, grad, exp_avg, exp_avg_sq, step0, frame_step, nsteps, lr, betas, eps, phase, order=None):
+    """One phase of the per-column Adam epoch (see include/dnmf_hip.h); tensors updated in place.  ``order`` (T)
+    int32: the frames sorted by ``frame_step`` (speed only)."""
     for t, n in ((beta, "beta"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _f32(t, n)
     if grad is not None:
         _f32(grad, "grad")
     fs = _i32(frame_step, beta.device)
+    od = _i32(order, beta.device) if order is not None else None
     _lib.check(_lib.load().dnmf_adam_epoch(beta.data_ptr(), _ptr(grad), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
-                                           beta.shape[2], int(step0), fs.data_ptr(), int(nsteps), float(lr),
+                                           beta.shape[2], int(step0), fs.data_ptr(), _ptr(od), int(nsteps), float(lr),
                                            float(betas[0]), float(betas[1]), float(eps), int(phase), _stream()),
                "dnmf_adam_epoch")
 

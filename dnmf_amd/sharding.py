@@ -28,12 +28,15 @@ class EpochPlan:
 
     nsteps       optimiser steps in the epoch (global number of mini-batches)
     frame_step   (T_local,) int32: 0-based global index of the mini-batch that holds each local frame, -1 if none
+    order        (T_local,) int32: the local frames sorted by frame_step (threads of the Adam kernel that run together
+                 then walk through the same window of steps)
     groups       list of (local frame indices (int64, epoch order), frames per mini-batch): frames whose
                  mini-batches have the same size share one kernel launch (the mean of the loss runs over that size)
     batches      per global mini-batch: local frame indices (possibly empty) -- the step-by-step view
     """
     nsteps: int
     frame_step: torch.Tensor
+    order: torch.Tensor
     groups: list
     batches: list
 
@@ -59,7 +62,8 @@ def plan_epoch(perm: torch.Tensor, batch_size: int, t0: int, t1: int) -> EpochPl
     groups = [(torch.from_numpy(local[sizes == s]), int(s)) for s in sorted({batch_size, tail or batch_size}, reverse=True)]
     groups = [g for g in groups if g[0].numel()]
     counts = np.bincount(steps, minlength=nsteps).tolist()
-    return EpochPlan(nsteps=nsteps, frame_step=torch.from_numpy(frame_step), groups=groups,
+    order = np.argsort(frame_step, kind="stable").astype(np.int32)
+    return EpochPlan(nsteps=nsteps, frame_step=torch.from_numpy(frame_step), order=torch.from_numpy(order), groups=groups,
                      batches=_LazySplit(torch.from_numpy(local), counts))
 
 

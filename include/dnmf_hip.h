@@ -239,10 +239,15 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
  *   phase 0: the frame_step[t] zero-gradient steps before its mini-batch (then run K2 on all frames),
  *   phase 1: the step with grad[:, :, t] and the zero-gradient steps after it.
  * beta, exp_avg, exp_avg_sq (10,3,T) are the optimiser's own tensors, updated in place; step0 = steps taken
- * before this epoch.  Same arithmetic as torch.optim.Adam (amsgrad off, weight_decay 0, maximize off). */
+ * before this epoch.  torch.optim.Adam with amsgrad off, weight_decay 0, maximize off: the step with a gradient is
+ * torch's fp32 arithmetic literally; a run of zero-gradient steps is evaluated in closed form (m b1^i, v b2^i, the
+ * increments of p summed in double, ending when m underflows), within 1e-6 of the displacement of the step-by-step
+ * fp32 evaluation.
+ *   order  NULL, or (T) a permutation of the frames sorted by frame_step: thread r of the launch takes frame
+ *          order[r], so the lanes of a wave walk through the same window of steps (speed only). */
 int dnmf_adam_epoch(float *beta, const float *grad, float *exp_avg, float *exp_avg_sq, int T, long step0,
-                    const int *frame_step, int nsteps, double lr, double beta1, double beta2, double eps,
-                    int phase, dnmf_stream_t stream);
+                    const int *frame_step, const int *order, int nsteps, double lr, double beta1, double beta2,
+                    double eps, int phase, dnmf_stream_t stream);
 
 /* ---- synthetic input: the render loop of the simulator ------------------------------------------------
  * WUtils/Simulator.py:66-73 (generate_video) with simulate_cell (:197-212): frame t0+t receives, neuron by

@@ -583,6 +583,64 @@ def test_recon_image_from_lists(M, O, sz, K, sigma):
     assert bool((S[:, P:] == -1.0).all())
 
 
+def test_adam_epoch_against_torch_steps(M):
+    """dnmf_adam_epoch (gradient step literal, zero-gradient runs in closed form) against torch.optim.Adam stepped 1500
+    times per epoch with the gradient of each column injected at its own step: two epochs, so the second starts from
+    moments the first left behind; columns without a mini-batch coast all the way.  torch in float64 is the yardstick:
+    the fused epoch must sit within a few fp32 ulps of beta of it (4e-7 + 2e-6 of the displacement), while torch's own
+    fp32 run is farther away (thousands of ~1e-5 increments rounded into an fp32 parameter one by one)."""
+    from dnmf_amd import ops
+    torch.manual_seed(3)
+    T, nsteps, lr = 96, 1500, 1e-3
+    beta = (torch.randn(10, 3, T, device="cuda") * 0.1 + 1.0).contiguous()
+    ref = beta.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=lr)
+    ref64 = beta.double().requires_grad_(True)
+    opt64 = torch.optim.Adam([ref64], lr=lr)
+    m = torch.zeros_like(beta)
+    v = torch.zeros_like(beta)
+    beta0 = beta.clone()
+    for epoch in range(2):
+        gen = torch.Generator().manual_seed(epoch)
+        fs = torch.randint(0, nsteps, (T,), generator=gen, dtype=torch.int32)
+        fs[::7] = -1                                   # frames in no mini-batch of this epoch
+        fs[1], fs[2] = 0, nsteps - 1                   # first and last step
+        order = torch.argsort(fs, stable=True).to(torch.int32)
+        ops.adam_epoch(beta, None, m, v, epoch * nsteps, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=0, order=order)
+        grad = torch.randn(10, 3, T, device="cuda") * 1e-2
+        grad[:, :, fs.cuda() < 0] = 0
+        ops.adam_epoch(beta, grad, m, v, epoch * nsteps, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=1, order=order)
+        by_step = {}
+        for t in range(T):
+            by_step.setdefault(int(fs[t]), []).append(t)
+        for s in range(nsteps):
+            g = torch.zeros_like(beta)
+            for t in by_step.get(s, ()):
+                g[:, :, t] = grad[:, :, t]
+            ref.grad = g
+            opt.step()
+            ref64.grad = g.double()
+            opt64.step()
+    disp = float((ref64.detach() - beta0).abs().max())
+    assert disp > 50 * lr
+    err = float((beta - ref64.detach()).abs().max())
+    err_torch32 = float((ref.detach() - ref64.detach()).abs().max())
+    assert err < 4e-7 + 2e-6 * disp, (err, err_torch32, disp)
+    assert float((beta - ref.detach()).abs().max()) < 4e-7 + 2e-6 * disp + err_torch32
+    st = opt64.state[ref64]
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=1e-4, atol=1e-20)
+    # the same epoch without the lane order gives the same numbers
+    b2, m2, v2 = beta0.clone(), torch.zeros_like(beta), torch.zeros_like(beta)
+    b3, m3, v3 = beta0.clone(), torch.zeros_like(beta), torch.zeros_like(beta)
+    fs = torch.randint(0, nsteps, (T,), generator=torch.Generator().manual_seed(9), dtype=torch.int32)
+    grad = torch.randn(10, 3, T, device="cuda") * 1e-2
+    for (b, mm, vv), od in (((b2, m2, v2), None), ((b3, m3, v3), torch.argsort(fs, stable=True).to(torch.int32))):
+        ops.adam_epoch(b, None, mm, vv, 0, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=0, order=od)
+        ops.adam_epoch(b, grad, mm, vv, 0, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=1, order=od)
+    assert torch.equal(b2, b3) and torch.equal(m2, m3) and torch.equal(v2, v3)
+
+
 @pytest.mark.parametrize("variant", ["table", "static"])
 @pytest.mark.parametrize("sz,K,T,sigma", [([96, 80, 1], 40, 5, 1.0), ([64, 48, 2], 100, 3, 0.7), ([40, 36, 3], 20, 4, 3.0),
                                           ([33, 47, 1], 7, 6, 0.8), ([32, 32, 1], 100, 3, 3.0), ([48, 40, 2], 80, 3, 1.6)])
