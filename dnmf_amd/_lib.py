@@ -43,7 +43,8 @@ SIGNATURES = {
     "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),
     "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp]),
-    "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _d, _d, _d, _d, _i, _vp]),
+    "dnmf_adam_epoch_workspace": (_sz, [_i]),
+    "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _d, _d, _d, _d, _i, _vp, _sz, _vp]),
     "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
     "dnmf_pack_footprints_lists": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dnmf_warp_gram_rhs_lists_workspace": (_sz, [_i, _i]),

@@ -234,9 +234,11 @@ def adam_epoch(beta, grad, exp_avg, exp_avg_sq, step0, frame_step, nsteps, lr, b
         _f32(grad, "grad")
     fs = _i32(frame_step, beta.device)
     od = _i32(order, beta.device) if order is not None else None
+    ws = torch.empty((4 * int(nsteps),), dtype=torch.float32, device=beta.device)
     _lib.check(_lib.load().dnmf_adam_epoch(beta.data_ptr(), _ptr(grad), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                            beta.shape[2], int(step0), fs.data_ptr(), _ptr(od), int(nsteps), float(lr),
-                                           float(betas[0]), float(betas[1]), float(eps), int(phase), _stream()),
+                                           float(betas[0]), float(betas[1]), float(eps), int(phase), ws.data_ptr(),
+                                           ws.numel() * 4, _stream()),
                "dnmf_adam_epoch")
 
 

@@ -244,10 +244,12 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
  * increments of p summed in double, ending when m underflows), within 1e-6 of the displacement of the step-by-step
  * fp32 evaluation.
  *   order  NULL, or (T) a permutation of the frames sorted by frame_step: thread r of the launch takes frame
- *          order[r], so the lanes of a wave walk through the same window of steps (speed only). */
+ *          order[r], so the lanes of a wave walk through the same window of steps (speed only).
+ *   workspace: dnmf_adam_epoch_workspace(nsteps) bytes (the step-dependent scalars of the epoch, rebuilt by each call) */
+size_t dnmf_adam_epoch_workspace(int nsteps);
 int dnmf_adam_epoch(float *beta, const float *grad, float *exp_avg, float *exp_avg_sq, int T, long step0,
                     const int *frame_step, const int *order, int nsteps, double lr, double beta1, double beta2,
-                    double eps, int phase, dnmf_stream_t stream);
+                    double eps, int phase, void *workspace, size_t workspace_bytes, dnmf_stream_t stream);
 
 /* ---- synthetic input: the render loop of the simulator ------------------------------------------------
  * WUtils/Simulator.py:66-73 (generate_video) with simulate_cell (:197-212): frame t0+t receives, neuron by
