@@ -171,24 +171,54 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         }
         if (NTAP != 8) lo[2] = 0, hi[2] = 0;
 
-        // ---- the tile's neuron list: ascending neuron indices, compacted into the wave's LDS strip ----------
+        // ---- the tile's neuron list: ascending neuron indices -------------------------------------------------
+        // Up to LISTS_NG neurons (nearly every tile) are picked out of the ballot masks with scalar bit operations;
+        // longer lists are compacted into the wave's LDS strip.
+        unsigned long long msk[NW];
         int n = 0;  // wave-uniform
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) {
             const bool hit = bx[wd][0] <= hi[0] && bx[wd][1] >= lo[0] && bx[wd][2] <= hi[1] && bx[wd][3] >= lo[1] &&
                              bx[wd][4] <= hi[2] && bx[wd][5] >= lo[2];
-            const unsigned long long m = __ballot(hit);
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (hit) lst[n + before] = lane + 64 * wd;
-            n += __builtin_popcountll(m);
+            msk[wd] = __ballot(hit);
+            n += __builtin_popcountll(msk[wd]);
         }
         if (n == 0) continue;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (n > LISTS_NG) {
+            int at = 0;
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) {
+                const unsigned long long m = msk[wd];
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if ((m >> lane) & 1) lst[at + before] = lane + 64 * wd;
+                at += __builtin_popcountll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         // neuron ids of the group that starts at list position g (wave-uniform scalars; -1 past the end)
         auto group_ids = [&](int g, int (&ks)[LISTS_NG]) {
+            if (n <= LISTS_NG) {  // g == 0: lowest set bits of the masks, in order
+                unsigned long long rem[NW];
+#pragma unroll
+                for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) {
+                    int k = -1;
+                    bool found = false;
+#pragma unroll
+                    for (int wd = 0; wd < NW; ++wd) {
+                        const bool take = !found && rem[wd] != 0;
+                        k = take ? 64 * wd + __builtin_ctzll(rem[wd]) : k;
+                        rem[wd] = take ? rem[wd] & (rem[wd] - 1) : rem[wd];
+                        found = found || take;
+                    }
+                    ks[i] = k;
+                }
+                return;
+            }
             const int mine = lst[min(g + (lane & 7), n - 1)];
 #pragma unroll
             for (int i = 0; i < LISTS_NG; ++i) ks[i] = g + i < n ? __builtin_amdgcn_readlane(mine, i) : -1;
