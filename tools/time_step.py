@@ -47,19 +47,8 @@ for label, timing in (("plain", None), ("with ops.TIMING", {})):
     torch.cuda.synchronize()
     print("5 sweeps %-16s %.2f ms each" % (label, 1e3 * (time.perf_counter() - t0) / 5))
 ops.TIMING = None
-for label, sync in (("sync each sweep", True), ("no sync", False)):
-    ts = []
-    torch.cuda.synchronize(); t00 = time.perf_counter()
-    for _ in range(8):
-        t0 = time.perf_counter(); sweep()
-        if sync:
-            torch.cuda.synchronize()
-        ts.append(1e3 * (time.perf_counter() - t0))
-    torch.cuda.synchronize()
-    print(label, ["%.1f" % t for t in ts], "total %.1f ms" % (1e3 * (time.perf_counter() - t00)))
-import cProfile, pstats
-pr = cProfile.Profile(); pr.enable()
-for _ in range(5):
-    sweep()
-torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+# per-sweep wall times: a host stall (CPU quota throttling, allocator re-mapping) shows as an outlier here
+ts = []
+for _ in range(12):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); sweep(); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+print("12 sweeps, each synchronised:", ["%.1f" % t for t in ts])
