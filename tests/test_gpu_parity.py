@@ -589,6 +589,38 @@ def test_recon_image_from_lists(M, O, sz, K, sigma):
     assert bool((S[:, P:] == -1.0).all())
 
 
+def test_neuron_list_gram_under_strong_warps(M, O):
+    """K3n's tile lists come from the taps its voxels actually have, whatever the warp does.  Forty frames whose warps
+    range from mild to violent (shifts up to the volume size, shear and scale of order one, quadratic terms that bend
+    the volume by tens of voxels, one frame with non-finite coefficients): the result must still be the dense
+    kernel's."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(123)
+    sz, K, T = [112, 96, 1], 60, 40
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, 1.0))
+    A[A < 1e-6] = 0
+    beta = O.identity_beta(T)
+    amp = np.logspace(-3, 1, T)                                  # per-frame strength
+    base = np.array([20.0, 0.3, 0.3, 0.3, 3e-3, 3e-3, 3e-3, 3e-3, 3e-3, 3e-3])
+    beta += (rng.randn(10, 3, T) * base[:, None, None] * amp[None, None, :]).astype(np.float32)
+    beta[:, 2] = O.identity_beta(T)[:, 2]
+    beta[4, 0, T - 1] = np.inf                                    # a frame without any finite bound
+    fp = make_fp(M, sz, K, T, pos, beta=beta, A=A)
+    frames = torch.rand(T, int(np.prod(sz)), device="cuda")
+    Gd, rd, _ = ops.warp_gram_rhs(fp.packed_footprints(), K, sz, fp.beta.detach(), None, frames)
+    Gn, rn, _ = ops.warp_gram_rhs_lists(fp.packed_lists(), K, sz, fp.beta.detach(), None, frames)
+    fin = torch.isfinite(Gd).all(dim=(1, 2)) & torch.isfinite(rd).all(dim=1)
+    assert int(fin.sum()) >= T - 1
+    for t in range(T):
+        if not bool(fin[t]):
+            continue
+        scale = max(float(Gd[t].abs().max()), 1e-30)
+        assert float((Gn[t] - Gd[t]).abs().max()) <= 2e-6 * scale, t
+        assert float((rn[t] - rd[t]).abs().max()) <= 2e-6 * max(float(rd[t].abs().max()), 1e-30), t
+    assert int((Gd.abs().amax(dim=(1, 2)) > 0).sum()) > T // 2   # most frames still see footprints
+
+
 def test_adam_epoch_against_torch_steps(M):
     """dnmf_adam_epoch (gradient step literal, zero-gradient runs in closed form) against torch.optim.Adam stepped 1500
     times per epoch with the gradient of each column injected at its own step: two epochs, so the second starts from
