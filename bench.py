@@ -51,6 +51,27 @@ def parse():
     return ap.parse_args()
 
 
+def other_kernels(evs, P, K, T_loc, tjson, key):
+    """HBM rooflines of the two other kernels of a sweep that move data, from the same HIP-event hooks."""
+    out = []
+    k2 = evs("warp_recon_grad")
+    if k2:
+        ms = 1e3 * sum(k2) / len(k2)
+        b = 8.0 * P * T_loc   # the reconstruction image and the frame, once each
+        out.append({"kernel": "warp_recon_grad_kernel (K2, incl. its finish kernel)", "bound": "hbm", "launch_ms": ms,
+                    "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": b / ms / 1e6 / HBM_PEAK_GBS, "traffic": tjson.get(f"{key.split('_K')[0]}_K2")})
+    rl = evs("recon_image_lists")
+    if rl:
+        ms = 1e3 * sum(rl) / len(rl)
+        b = 4.0 * P * T_loc   # the reconstruction image, written once
+        out.append({"kernel": "recon_lists_kernel (reconstruction image from neuron lists)", "bound": "hbm",
+                    "launch_ms": ms, "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                    "traffic": tjson.get(f"{key.split('_K')[0]}_recon_lists")})
+    return out
+
+
 def usable_cpus():
     """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -265,6 +286,7 @@ def main():
                 "unit": "TFLOP/s", "frac": dense_flops / (dense_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "traffic": tjson.get(key), "launch_ms": dense_ms, "flops_per_launch": dense_flops},
             "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps, "K2_motion_kernels": 1e3 * sum(k2) / args.steps},
+            "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy())

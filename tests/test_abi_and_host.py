@@ -54,6 +54,21 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     rc = lib.dnmf_warp_gram_rhs(addr, 16, 3, 0, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr, 8, None)
     assert rc in (-2, -4)  # alignment or workspace, never a launch
     assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 3 * 28 * 256 * 4
+    # the neuron-list entry points
+    assert lib.dnmf_pack_footprints_lists(addr, 4, 4, 1, 300, addr, addr, addr, addr, None) == -3   # K > 256
+    assert lib.dnmf_pack_footprints_lists(None, 4, 4, 1, 3, addr, addr, addr, addr, None) == -1
+    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 4000) == 4000 * 5 * 461 * 4
+    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, 5000, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr,
+                                      1 << 20, None, None)
+    assert rc == -3 and b"pattern slots" in lib.dnmf_last_error()
+    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, 10, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr,
+                                      8, None, None)
+    assert rc == -4
+    assert lib.dnmf_recon_image_lists(addr, addr, 3, 4, 4, 1, addr, 4, None, 2, addr, 8, None) == -2     # lds < P
+    assert lib.dnmf_mu_temporal_nbr(addr, addr, addr, 4, 3, 4, 1, addr, 12, None) == -3                   # NN not 8/16/32
+    assert lib.dnmf_adam_epoch_workspace(1000) == 16000
+    assert lib.dnmf_adam_epoch(addr, None, addr, addr, 4, 0, addr, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0, addr, 8, None) == -4
+    assert lib.dnmf_warp_recon_grad_workspace(512, 512, 1, 4000) == 4000 * 64 * 32 * 4 + 4000 * 4
     # C1: arguments are checked before RCCL is looked up
     assert lib.dnmf_comm_unique_id(None) == -1
     assert lib.dnmf_comm_init(None, addr, 2, 0) == -1
