@@ -372,9 +372,16 @@ class DeformableNMF:
         with torch.no_grad():
             frames, order = self._gather_frames(testloader)
             T_loc = frames.shape[0]
-            G, r = self._gram_rhs(frames, order)
             Csel = self.C.to(device, torch.float32)[:, order.long()].contiguous()
-            Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c, group=self.group, nbr=self._gram_nbr)
+            ly = self._lists_layout_for_fused_update(gamma_c)
+            if ly is not None:
+                # K3n leaves its slot tables in the workspace and K4 reads them there: no dense (T,K,K) in between
+                _, _, self._ws_k3 = ops.warp_gram_rhs_lists(ly, K, fp.sz_list, fp.beta.detach(), order, frames,
+                                                            workspace=self._ws_k3, finish=False)
+                Cnew = ops.mu_temporal_slots(ly, self._ws_k3, fp.sz_list, Csel.clone(), iter_c)
+            else:
+                G, r = self._gram_rhs(frames, order)
+                Cnew = _mu_temporal(G, r, Csel, gamma_c, iter_c, group=self.group, nbr=self._gram_nbr)
             C = self.C.to(device, torch.float32).clone()
             C[:, order.long()] = Cnew
             self.C = C
@@ -395,6 +402,19 @@ class DeformableNMF:
                     yi = ops.image_iwarp(frames, order[s:s + 256], fp.sz_list, fp.beta.detach(), order[s:s + 256])
                     Yi[..., s:s + 256] = yi.view(-1, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
             return A_t, Yi, Yv
+
+    def _lists_layout_for_fused_update(self, gamma_c):
+        """The K3n layout when update_footprints can run as K3n + K4-on-slots (one channel, no neighbour term, the
+        kernel choice allows K3n and the pattern is narrow enough for the per-row lists); else None."""
+        fp = self.fp
+        if not (gamma_c is None or gamma_c == 0) or len(self._channels()) != 1 or fp.K > 256:
+            return None
+        if self.gram_kernel not in ('auto', 'lists'):
+            return None
+        ly = fp.packed_lists()
+        if ly["nbr"] is None or ly["nslot"] > ops.LISTS_MAX_SLOTS:
+            return None
+        return ly if (self.gram_kernel == 'lists' or ly["boxfrac"] < LISTS_BOXFRAC_LIMIT) else None
 
     def _gram_rhs(self, frames, order):
         """Per-frame Gram matrices and right-hand sides under the current warp, summed over the channels."""

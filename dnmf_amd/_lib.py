@@ -39,6 +39,8 @@ SIGNATURES = {
                                           _sz, _vp, _vp]),
     "dnmf_mu_temporal": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "dnmf_mu_temporal_nbr": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp]),
+    "dnmf_mu_temporal_slots": (_i, [_vp, _i, _i, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp]),
+    "dnmf_warp_gram_rhs_lists_chunks": (_i, [_i, _i, _i, _i]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
     "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),

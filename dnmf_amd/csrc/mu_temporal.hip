@@ -76,6 +76,46 @@ __global__ __launch_bounds__(256) void mu_temporal_nbr_kernel(const float *__res
     if (live) C[(long)k * ldc + t] = (float)c;
 }
 
+// The same again, reading the slot tables K3n left in its workspace instead of a dense G: entry (k,l) is the ordered
+// sum over the chunks of slot pair_slot[k][l] -- exactly what gram_lists_finish_kernel would have written -- and r[k]
+// the sum of slot k.  Saves writing and re-reading (T,K,K).
+template <int NN>
+__global__ __launch_bounds__(256) void mu_temporal_slots_kernel(const float *__restrict__ slab, int nchunks, int nslot,
+                                                                const int *__restrict__ pair_slot,
+                                                                float *__restrict__ C, long ldc, int K, int iters,
+                                                                const int *__restrict__ nbr) {
+    __shared__ double cs[256];
+    const int t = blockIdx.x;
+    const int k = threadIdx.x;
+    const float *src = slab + (long)t * nchunks * nslot;
+    const bool live = k < K;
+    auto slot_sum = [&](int slot) {
+        float s = 0.0f;
+        if (slot != nslot - 1)
+            for (int c = 0; c < nchunks; ++c) s += src[(long)c * nslot + slot];
+        return s;
+    };
+    double g[NN];
+    int li[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        li[j] = live ? nbr[k * NN + j] : 0;
+        g[j] = live ? (double)slot_sum(pair_slot[(long)li[j] * K + k]) : 0.0;
+    }
+    const double rk = live ? (double)slot_sum(k) : 0.0;
+    double c = live ? (double)C[(long)k * ldc + t] : 0.0;
+    for (int it = 0; it < iters; ++it) {
+        cs[k] = c;
+        __syncthreads();
+        double dot = 0.0;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) dot = fma(g[j], cs[li[j]], dot);
+        c = (c * rk) / (dot + 1e-32);
+        __syncthreads();
+    }
+    if (live) C[(long)k * ldc + t] = (float)c;
+}
+
 // one round with the temporal-smoothness term on an fp64 state (Jacobi: all of Cin is the old iterate)
 __global__ __launch_bounds__(256) void mu_temporal_step_kernel(const float *__restrict__ G, const float *__restrict__ r,
                                                                const double *__restrict__ Cin, double *__restrict__ Cout,
@@ -143,6 +183,26 @@ int dnmf_mu_temporal_nbr(const float *G, const float *r, float *C, long ldc, int
     else
         hipLaunchKernelGGL(mu_temporal_nbr_kernel<32>, grid, block, 0, st, G, r, C, ldc, K, iters, nbr);
     return check_launch("dnmf_mu_temporal_nbr");
+}
+
+int dnmf_mu_temporal_slots(const float *slab, int nchunks, int nslot, const int *pair_slot, float *C, long ldc, int K,
+                           int T, int iters, const int *nbr, int NN, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(slab && pair_slot && C && nbr, DNMF_E_NULL, "dnmf_mu_temporal_slots: NULL buffer");
+    DNMF_REQUIRE(K > 0 && T > 0 && ldc >= T && iters >= 0 && nchunks > 0 && nslot > K, DNMF_E_SHAPE,
+                 "dnmf_mu_temporal_slots: K=%d T=%d ldc=%ld iters=%d nchunks=%d nslot=%d", K, T, ldc, iters, nchunks, nslot);
+    DNMF_REQUIRE(K <= 256 && (NN == 8 || NN == 16 || NN == 32), DNMF_E_UNSUPPORTED,
+                 "dnmf_mu_temporal_slots: K=%d (<= 256), NN=%d (8, 16 or 32)", K, NN);
+    if (iters == 0) return DNMF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)T), block(K <= 64 ? 64 : (K <= 128 ? 128 : 256));
+    if (NN == 8)
+        hipLaunchKernelGGL(mu_temporal_slots_kernel<8>, grid, block, 0, st, slab, nchunks, nslot, pair_slot, C, ldc, K, iters, nbr);
+    else if (NN == 16)
+        hipLaunchKernelGGL(mu_temporal_slots_kernel<16>, grid, block, 0, st, slab, nchunks, nslot, pair_slot, C, ldc, K, iters, nbr);
+    else
+        hipLaunchKernelGGL(mu_temporal_slots_kernel<32>, grid, block, 0, st, slab, nchunks, nslot, pair_slot, C, ldc, K, iters, nbr);
+    return check_launch("dnmf_mu_temporal_slots");
 }
 
 int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K, int T,

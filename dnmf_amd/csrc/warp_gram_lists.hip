@@ -483,7 +483,7 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
                              const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
                              unsigned long long *counters, dnmf_stream_t stream) {
     using namespace dnmf;
-    DNMF_REQUIRE(At && bbox && pair_slot && beta && frames && G && r && workspace, DNMF_E_NULL,
+    DNMF_REQUIRE(At && bbox && pair_slot && beta && frames && workspace && (!G == !r), DNMF_E_NULL,
                  "dnmf_warp_gram_rhs_lists: NULL buffer");
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && nslot > K, DNMF_E_SHAPE,
                  "dnmf_warp_gram_rhs_lists: X=%d Y=%d Z=%d K=%d T=%d B=%d nslot=%d", X, Y, Z, K, T, B, nslot);
@@ -520,9 +520,20 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
         else if (nw == 2) launch_lists_t<4, 2>(p, nwg, lds, st);
         else launch_lists_t<4, 4>(p, nwg, lds, st);
     }
-    hipLaunchKernelGGL(gram_lists_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, p.slab, p.nchunks, nslot, pair_slot,
-                       K, G, r);
+    if (G)
+        hipLaunchKernelGGL(gram_lists_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, p.slab, p.nchunks, nslot,
+                           pair_slot, K, G, r);
     return check_launch("dnmf_warp_gram_rhs_lists");
+}
+
+int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B) {
+    using namespace dnmf;
+    if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
+    const Volume vol = make_volume(X, Y, Z);
+    int lgx, lgz, nty, ntz, ntiles, nchunks, chunk_len;
+    lists_tile_shape(vol, lgx, lgz, nty, ntz, ntiles);
+    lists_choose_chunks(ntiles, B, nchunks, chunk_len);
+    return nchunks;
 }
 
 }  // extern "C"

@@ -308,8 +308,9 @@ LISTS_MAX_SLOTS = 3800
 LISTS_COUNTERS = None
 
 
-def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, workspace=None):
-    """K3n.  Returns G (B,K,K), r (B,K), workspace."""
+def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, workspace=None, finish=True):
+    """K3n.  Returns G (B,K,K), r (B,K), workspace; with ``finish=False`` G and r are None and the slot tables stay
+    in ``workspace`` for ``mu_temporal_slots``."""
     global LISTS_COUNTERS
     X, Y, Z = (int(s) for s in sz)
     dev = beta.device
@@ -324,8 +325,8 @@ def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, work
     need = lib.dnmf_warp_gram_rhs_lists_workspace(nslot, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
-    G = torch.empty((B, K, K), dtype=torch.float32, device=dev)
-    r = torch.empty((B, K), dtype=torch.float32, device=dev)
+    G = torch.empty((B, K, K), dtype=torch.float32, device=dev) if finish else None
+    r = torch.empty((B, K), dtype=torch.float32, device=dev) if finish else None
     counters = None
     if TIMING is not None:
         if LISTS_COUNTERS is None:
@@ -334,10 +335,27 @@ def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, work
     with _timed("warp_gram_rhs_lists"):
         rc = lib.dnmf_warp_gram_rhs_lists(
             layout["At"].data_ptr(), layout["bbox"].data_ptr(), layout["pair_slot"].data_ptr(), nslot, K, X, Y, Z,
-            beta.data_ptr(), beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(),
-            r.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())
+            beta.data_ptr(), beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), _ptr(G),
+            _ptr(r), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())
     _lib.check(rc, "dnmf_warp_gram_rhs_lists")
     return G, r, workspace
+
+
+def mu_temporal_slots(layout, workspace, sz, C, iters: int):
+    """K4 straight from the slot tables ``warp_gram_rhs_lists(..., finish=False)`` left in ``workspace``; C (K,T) fp32
+    updated in place (T = the frames of that launch).  Needs ``layout["nbr"]``."""
+    X, Y, Z = (int(s) for s in sz)
+    if not (C.is_cuda and C.dtype == torch.float32 and C.stride(1) == 1):
+        raise ValueError("mu_temporal_slots: C must be float32 CUDA with unit inner stride")
+    K, T = C.shape
+    lib = _lib.load()
+    nbr = layout["nbr"]
+    with _timed("mu_temporal_slots"):
+        rc = lib.dnmf_mu_temporal_slots(workspace.data_ptr(), lib.dnmf_warp_gram_rhs_lists_chunks(X, Y, Z, T),
+                                        layout["nslot"], layout["pair_slot"].data_ptr(), C.data_ptr(), C.stride(0), K, T,
+                                        int(iters), nbr.data_ptr(), nbr.shape[1], _stream())
+    _lib.check(rc, "dnmf_mu_temporal_slots")
+    return C
 
 
 class Communicator:

@@ -153,13 +153,15 @@ int dnmf_warp_gram_rhs_sparse_lt(const float *Aps, int Ks, int K, const int *ord
  *   non-zeros of each footprint; pair_slot (K,K) int32 and *nslot (one int32, DEVICE) = the static pattern of G:
  *   slots [0,K) hold r, the following ones the pairs (k,l) whose boxes can meet under one tap cell, the last one
  *   (nslot-1) collects everything else.  The caller reads *nslot back once to size the workspace.
- * dnmf_warp_gram_rhs_lists: other arguments and results as dnmf_warp_gram_rhs (G dense (B,K,K), r (B,K));
+ * dnmf_warp_gram_rhs_lists: other arguments and results as dnmf_warp_gram_rhs (G dense (B,K,K), r (B,K); both NULL:
+ *   the slot tables are left in the workspace for dnmf_mu_temporal_slots);
  *   nslot <= 3800 (DNMF_E_UNSUPPORTED beyond: the footprints overlap too much, use K3 / K3s);
  *   workspace: dnmf_warp_gram_rhs_lists_workspace(nslot,B) bytes;
  *   counters: NULL, or 2 x uint64 INCREMENTED by the (tile, neuron) evaluations and the (tile, pair) sums done. */
 int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float *At, int *bbox, int *pair_slot,
                                int *nslot, dnmf_stream_t stream);
 size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int B);
+int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B); /* chunk tables per frame the launch will write */
 int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, int nslot, int K, int X, int Y,
                              int Z, const float *beta, int T, const int *times, int B, const float *frames, long ldf,
                              const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
@@ -189,6 +191,11 @@ int dnmf_mu_temporal(const float *G, const float *r, float *C, long ldc, int K, 
  * results (the skipped terms are exact zeros), NN instead of K terms per row and round. */
 int dnmf_mu_temporal_nbr(const float *G, const float *r, float *C, long ldc, int K, int T, int iters, const int *nbr,
                          int NN, dnmf_stream_t stream);
+/* The same straight from the slot tables of K3n: call dnmf_warp_gram_rhs_lists with G = r = NULL (the tables then stay
+ * in its workspace as (T, nchunks, nslot) floats, nchunks = dnmf_warp_gram_rhs_lists_chunks(X,Y,Z,T)) and hand the
+ * workspace in as `slab`.  Bit-identical to finishing into a dense G first; saves writing and re-reading (T,K,K). */
+int dnmf_mu_temporal_slots(const float *slab, int nchunks, int nslot, const int *pair_slot, float *C, long ldc, int K,
+                           int T, int iters, const int *nbr, int NN, dnmf_stream_t stream);
 int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, double *Cout, long ldc, int K,
                           int T, double gamma, const double *c_left, const double *c_right,
                           dnmf_stream_t stream);

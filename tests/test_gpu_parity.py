@@ -555,6 +555,9 @@ def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma):
         assert bool((Gn[:, ~pat] == 0).all())
         assert all(bool(pat[k, ly["nbr"][k].long()].sum() == pat[k].sum()) for k in range(K))
         assert torch.equal(ops.mu_temporal(Gn, rn, C0.clone(), 9, nbr=ly["nbr"]), ops.mu_temporal(Gn, rn, C0.clone(), 9))
+        # ... and so does K4 reading the slot tables directly (no dense G in between)
+        _, _, ws2 = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames, finish=False)
+        assert torch.equal(ops.mu_temporal_slots(ly, ws2, sz, C0.clone(), 9), ops.mu_temporal(Gn, rn, C0.clone(), 9))
     # a subset of frames in another order, through the model switch
     dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
     dn.fp, dn.gram_kernel = fp, 'lists'
