@@ -47,11 +47,13 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     float bt[30];
     load_beta(beta, T, times[b], bt);
 
-    float acc[NA][ND];
+    // y and z are fixed along a thread's rows, so inside the loop only the moments of the per-voxel term over x are
+    // accumulated: mom[m][d] = sum_i (resid g_d)_i x_i^m, m = 0, 1, 2; the ten basis sums follow from them afterwards
+    float mom[3][ND];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int d = 0; d < ND; ++d) acc[a][d] = 0.0f;
+        for (int d = 0; d < ND; ++d) mom[m][d] = 0.0f;
     float sq = 0.0f;
     const int YZ = vol.Y * vol.Z;
     const int bu = blockIdx.x % nub, bx = blockIdx.x / nub;
@@ -114,14 +116,25 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
             // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
             const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
             sq = fmaf(resid, resid, sq);
-            const float xf = (float)x;
-            const float basis[10] = {1.0f, xf, yf, xf * xf, yf * yf, xf * yf, zf, zf * zf, xf * zf, yf * zf};
+            const float xf = (float)x, xx = xf * xf;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const float gd = resid * g[d];
-#pragma unroll
-                for (int a = 0; a < NA; ++a) acc[a][d] = fmaf(basis[a], gd, acc[a][d]);
+                mom[0][d] += gd;
+                mom[1][d] = fmaf(xf, gd, mom[1][d]);
+                mom[2][d] = fmaf(xx, gd, mom[2][d]);
             }
+        }
+    }
+    // basis order [1, x, y, x^2, y^2, xy, z, z^2, xz, yz] (BASIS_ID maps it to the reference's)
+    float acc[NA][ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        acc[0][d] = mom[0][d], acc[1][d] = mom[1][d], acc[2][d] = yf * mom[0][d], acc[3][d] = mom[2][d];
+        acc[4][d] = (yf * yf) * mom[0][d], acc[5][d] = yf * mom[1][d];
+        if (HASZ) {
+            acc[6][d] = zf * mom[0][d], acc[7][d] = (zf * zf) * mom[0][d], acc[8][d] = zf * mom[1][d];
+            acc[9][d] = (yf * zf) * mom[0][d];
         }
     }
 
