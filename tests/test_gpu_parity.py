@@ -386,6 +386,61 @@ def test_full_size_properties(M):
     assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
 
 
+def test_full_size_neuron_list_path(M):
+    """The bench's default path at its geometry (512x512, K=100): K3n, the list reconstruction and K4 on the slot
+    tables, through the same size-independent properties -- identity warp => A^T A; integer shifts => Gram of the
+    shifted footprints; S = A.C against a float64 product; the fused update_footprints equals the two-step one bit
+    for bit; a full sweep through the model leaves finite, non-negative traces."""
+    from dnmf_amd import ops
+    torch.manual_seed(0)
+    sz, K, T = [512, 512, 1], 100, 8
+    pos = torch.rand(K, 3) * torch.tensor([512.0, 512.0, 0.0])
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    dn.verbose = False
+    fp = dn.fp
+    frames = torch.rand(T, 512 * 512, device="cuda")
+    with torch.no_grad():
+        fp.beta[0, 0, 1] = 3.0       # frame 1: shift +3 px in x
+        fp.beta[0, 1, 2] = -2.0      # frame 2: shift -2 px in y
+    ly = fp.packed_lists()
+    assert ly["boxfrac"] < 2 and ly["nbr"] is not None
+    G, r, _ = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames)
+    A2 = fp.A.reshape(-1, K).double()
+    G0 = A2.T @ A2
+    scale = float(G0.abs().max())
+    for t in (0, 3, 7):
+        assert float((G[t].double() - G0).abs().max()) < 2e-5 * scale
+        rt = A2.T @ frames[t].double()
+        assert float((r[t].double() - rt).abs().max()) < 2e-5 * float(rt.abs().max())
+    A3 = fp.A.reshape(512, 512, K)
+    sh = torch.zeros_like(A3)
+    sh[:-3] = A3[3:]
+    S2 = sh.reshape(-1, K).double()
+    assert float((G[1].double() - S2.T @ S2).abs().max()) < 2e-5 * scale
+    sh = torch.zeros_like(A3)
+    sh[:, 2:] = A3[:, :-2]
+    S2 = sh.reshape(-1, K).double()
+    assert float((G[2].double() - S2.T @ S2).abs().max()) < 2e-5 * scale
+    assert torch.equal(G, G.transpose(1, 2))
+    # reconstruction image
+    C = torch.rand(K, T, device="cuda")
+    S = ops.recon_image_lists(ly, K, sz, C, list(range(T)))
+    want = (A2 @ C.double()).T
+    assert float((S[:, :512 * 512].double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    # fused update_footprints == Gram, then K4
+    dn.C = C.clone()
+    test = M.ResidentLoader(frames, sz, 4)
+    dn.update_footprints(test, 4, sz, gamma_c=0, iter_c=50, return_dense=False)
+    two_step = ops.mu_temporal(G, r, C.clone(), 50, nbr=ly["nbr"])
+    assert torch.equal(dn.C, two_step)
+    # a sweep through the model
+    opt = torch.optim.Adam([fp.beta], lr=1e-5)
+    train = M.ResidentLoader(frames, sz, 4, shuffle=True, generator=torch.Generator().manual_seed(0))
+    dn.update_motion(train, opt, gamma=1, epochs=1)
+    dn.update_footprints(test, 4, sz, gamma_c=0, iter_c=50, return_dense=False)
+    assert bool((dn.C >= 0).all()) and bool(torch.isfinite(dn.C).all()) and bool(torch.isfinite(fp.beta).all())
+
+
 def test_G8_device_simulator(M):
     """The GPU render loop + normalisation against the reference video (noise passed in: the reference
     draws it from the CPU generator)."""
