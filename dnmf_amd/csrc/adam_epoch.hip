@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void adam_epoch_kernel(float *__restrict__ bet
         // steps until m b1^i is below the smallest fp32 denormal (2^-149): every later term is exactly zero
         int live_steps = 0;
         if (m != 0.0f) {
-            const float need = (__log2f(fabsf(m)) + 150.0f) / -__log2f((float)b1);
-            live_steps = need >= (float)k ? k : max(0, (int)need + 2);
+            // (a denormal m may read as log2 = -inf: no live steps, which is what its product with b1 gives anyway)
+            const float need = fmaxf((__log2f(fabsf(m)) + 150.0f) / -__log2f((float)b1), -1.0f);
+            live_steps = (need >= (float)k || !(b1 < 1.0)) ? k : max(0, (int)need + 2);  // b1 >= 1: m never decays
             live_steps = min(live_steps, k);
         }
         double pb1 = 1.0, pb2 = 1.0, acc = 0.0;
