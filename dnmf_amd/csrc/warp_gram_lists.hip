@@ -32,6 +32,8 @@
 namespace dnmf {
 
 constexpr int LISTS_NG = 4;      // neurons evaluated together (register slots); longer lists are cut into groups
+constexpr int LISTS_LGV = 2;      // log2 of the voxels per lane (consecutive x positions, interleaved by lane)
+constexpr int LISTS_VPL = 1 << LISTS_LGV;
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
 constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items per launch
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x (3800 + 256) words of LDS per workgroup
@@ -52,7 +54,7 @@ struct ListParams {
     const int *frame_ids;
     float *slab;  // (B, nchunks, nslot)
     int nchunks, chunk_len;
-    int lgx, lgz;  // tile = (4 << lgx) x 16 x (1 << lgz) voxels, lgx + lgz = 2
+    int lgx, lgz;  // tile = (LISTS_VPL << lgx) x 16 x (1 << lgz) voxels, lgx + lgz = 2
     int nty, ntz, ntiles;
     unsigned long long *counters;  // optional: [0] += (tile, neuron) evaluations, [1] += (tile, pair) sums
 };
@@ -137,13 +139,13 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         const int y = (qy << 4) + ly, z = (qz << lgz) + lz;
 
         // ---- taps of this lane's four voxels ------------------------------------------------------------
-        unsigned off[4][NTAP];  // byte offset of the tap inside a neuron's plane
-        float w[4][NTAP];
-        float yv[4];
+        unsigned off[LISTS_VPL][NTAP];  // byte offset of the tap inside a neuron's plane
+        float w[LISTS_VPL][NTAP];
+        float yv[LISTS_VPL];
         int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int x = (qx << (lgx + 2)) + (v << lgx) + lx;
+        for (int v = 0; v < LISTS_VPL; ++v) {
+            const int x = (qx << (lgx + LISTS_LGV)) + (v << lgx) + lx;
 #pragma unroll
             for (int c = 0; c < NTAP; ++c) off[v][c] = 0u, w[v][c] = 0.0f;
             yv[v] = 0.0f;
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
 #pragma unroll
             for (int i = 0; i < LISTS_NG; ++i) ks[i] = g + i < n ? __builtin_amdgcn_readlane(mine, i) : -1;
         };
-        auto eval = [&](int k, float (&a)[4]) {
+        auto eval = [&](int k, float (&a)[LISTS_VPL]) {
             const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < LISTS_VPL; ++v) {
                 // the offsets are re-materialised as 32-bit values here so that the loads take the
                 // (scalar base + 32-bit vector offset) form; hoisted out of the neuron loop they become 64-bit pairs
                 unsigned o[NTAP];
@@ -241,11 +243,11 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
                 a[v] = s;
             }
         };
-        auto dot4 = [&](const float (&a)[4], const float (&c)[4]) {
+        auto dot4 = [&](const float (&a)[LISTS_VPL], const float (&c)[LISTS_VPL]) {
             float s = a[0] * c[0];
-            s = fmaf(a[1], c[1], s);
-            s = fmaf(a[2], c[2], s);
-            return fmaf(a[3], c[3], s);
+#pragma unroll
+            for (int v = 1; v < LISTS_VPL; ++v) s = fmaf(a[v], c[v], s);
+            return s;
         };
         // one lane, one LDS add (an atomic builtin here is rewritten into a cross-lane reduction loop)
         auto add_slot = [&](int slot, float total_in_last_lane) {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         };
         // the N leading neurons of a group: their warped values, then the sums among themselves and against the frame;
         // straight-line code, so that the row requests overlap and the N + N(N+1)/2 reduction trees interleave
-        auto within = [&](auto nn, const int (&ks)[LISTS_NG], float (&a)[LISTS_NG][4]) {
+        auto within = [&](auto nn, const int (&ks)[LISTS_NG], float (&a)[LISTS_NG][LISTS_VPL]) {
             constexpr int N = decltype(nn)::value;
 #pragma unroll
             for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         n_eval += n, n_pair += n * (n + 1) / 2;
         for (int g1 = 0; g1 < n; g1 += LISTS_NG) {
             int kA[LISTS_NG];
-            float aA[LISTS_NG][4];
+            float aA[LISTS_NG][LISTS_VPL];
             group_ids(g1, kA);
             using std::integral_constant;
             switch (min(n - g1, LISTS_NG)) {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
             // pairs of this (then full) group with every later group
             for (int g2 = g1 + LISTS_NG; g2 < n; g2 += LISTS_NG) {
                 int kB[LISTS_NG];
-                float aB[LISTS_NG][4];
+                float aB[LISTS_NG][LISTS_VPL];
                 group_ids(g2, kB);
 #pragma unroll
                 for (int j = 0; j < LISTS_NG; ++j) {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void lists_pairs_kernel(const int *__restrict_
 static void lists_tile_shape(const Volume &vol, int &lgx, int &lgz, int &nty, int &ntz, int &ntiles) {
     lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
     lgx = 2 - lgz;
-    const int tx = 4 << lgx, tz = 1 << lgz;
+    const int tx = LISTS_VPL << lgx, tz = 1 << lgz;
     ntz = (vol.Z + tz - 1) / tz;
     nty = (vol.Y + 15) / 16;
     ntiles = ((vol.X + tx - 1) / tx) * nty * ntz;
