@@ -35,6 +35,7 @@ DENSE_RETURN_LIMIT = 1 << 31
 # update_motion keeps the reconstruction images of all T frames resident below this many bytes
 LISTS_BOXFRAC_LIMIT = 6.0   # 'auto' takes K3n below this mean number of footprint boxes per voxel
 RECON_CACHE_LIMIT = 64 << 30
+K2_MAX_FRAMES = 32768       # frames per K2 launch (they ride on gridDim.y)
 
 
 def _sz_list(sz):
@@ -118,6 +119,11 @@ class ExponentialFP(nn.Module):
         self._lists_version = None
         self.use_lists = True   # reconstruction image from neuron lists when the footprints are compact
 
+    def invalidate_layouts(self):
+        """Forget every packed copy of ``A``.  The packed copies are keyed on ``(A.data_ptr(), A._version)``, which a
+        kernel that writes ``A`` through its raw pointer (K6) does not change: such callers say so here."""
+        self._packed = self._sparse = self._sparse_pairs = self._lists = None
+
     @staticmethod
     def quadratic_basis(P):
         """[1, x, y, z, x^2, y^2, z^2, xy, xz, yz] (reference :46-51)."""
@@ -139,22 +145,23 @@ class ExponentialFP(nn.Module):
         return ops.pack_footprints(sub)
 
     def recon_image(self, C, times, out=None):
-        """S[b] = A . C[:, times[b]]: from the neuron lists when the footprints are compact (``use_lists``), else
-        ``dnmf_recon_image`` (fp32 MFMA), by groups of 112 neurons when K > 127."""
+        """S[b] = A . C[:, times[b]] as (B, >= ops.halo_voxels(sz)) rows in the halo layout K2 gathers from: from the
+        neuron lists when the footprints are compact (``use_lists``), else ``dnmf_recon_image`` (fp32 MFMA), by groups
+        of 112 neurons when K > 127."""
         if self.use_lists and self.K <= 256:
             ly = self.packed_lists()
             if ly["boxfrac"] < LISTS_BOXFRAC_LIMIT:
                 return ops.recon_image_lists(ly, self.K, self.sz_list, C, times, out=out)
         if self.K <= 127:
-            return ops.recon_image(self.packed_footprints(), self.K, C, times, out=out)
+            return ops.recon_image(self.packed_footprints(), self.K, self.sz_list, C, times, out=out)
         for n, s0 in enumerate(range(0, self.K, 112)):
             cols = list(range(s0, min(self.K, s0 + 112)))
-            part = ops.recon_image(self.packed_columns(cols), len(cols), C[cols].contiguous(), times,
+            part = ops.recon_image(self.packed_columns(cols), len(cols), self.sz_list, C[cols].contiguous(), times,
                                    out=out if n == 0 else None)
             if n == 0:
                 out = part
             else:
-                out[:part.shape[0]] += part
+                out[:part.shape[0], :part.shape[1]] += part
         return out
 
     def _zorder(self):
@@ -285,6 +292,10 @@ class DeformableNMF:
         # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
         self.group = None
         self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
+        self._spatial_buf = None   # A1 (P,K) and C_s (K,K) of spatial_step, one buffer = one all-reduce
+        self.time_spatial = False
+        self.last_spatial_ms = None
+        self._warned = set()
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
     @staticmethod
@@ -326,27 +337,50 @@ class DeformableNMF:
     def spatial_step(self, registered, D=None, gamma=None, frame_ids=None):
         """One multiplicative update of ``fp.A`` from the registered frames this process holds (the update the
         reference leaves commented out at :174, on the flattened voxel axis): K5 on the local frames, ONE all-reduce
-        (sum) of ``A1`` (P,K) and ``C_s`` (K,K) over ``self.group`` when the T axis is sharded, then K6 -- every rank
-        ends with the same footprints.  ``registered`` (T_local,P) fp32 CUDA rows, ``D`` None or (X,Y,Z,K)."""
+        (sum) of the buffer that holds ``A1`` (P,K) and ``C_s`` (K,K) over ``self.group`` when the T axis is sharded,
+        then K6 -- every rank ends with the same footprints.  ``registered`` (T_local,P) fp32 CUDA rows, ``D`` None
+        or (X,Y,Z,K).  ``self.last_spatial_ms`` receives (K5, all-reduce, K6) HIP-event times when
+        ``self.time_spatial`` is set."""
         fp = self.fp
-        if fp.K > 128:
-            raise NotImplementedError("spatial_step: K > 128")
+        P, K = fp.P, fp.K
         C = self.C.to(device, torch.float32).contiguous()
-        A1, Cs = ops.spatial_accum(registered, C, frame_ids=frame_ids, times=frame_ids)
+        # A1 and C_s live in one buffer so that the exchange is a single collective
+        if self._spatial_buf is None or self._spatial_buf.numel() != P * K + K * K:
+            self._spatial_buf = torch.empty((P * K + K * K,), dtype=torch.float32, device=device)
+        buf = self._spatial_buf
+        A1, Cs = buf[:P * K].view(P, K), buf[P * K:].view(K, K)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_spatial else None
+        if ev:
+            ev[0].record()
+        if K <= 128:
+            ops.spatial_accum(registered, C, frame_ids=frame_ids, times=frame_ids, A1=A1, Cs=Cs, accumulate=False)
+        else:  # K5 holds 8 trace blocks per wave: columns of A1 by groups of 128 neurons; C C^T is tiny
+            Cl = C if frame_ids is None else C[:, torch.as_tensor(frame_ids, device=C.device).long()]
+            for s0 in range(0, K, 128):
+                part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=frame_ids)
+                A1[:, s0:s0 + 128] = part
+            Cs.copy_((Cl.double() @ Cl.double().T).float())
+        if ev:
+            ev[1].record()
         if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
             if torch.distributed.get_backend(self.group) == "nccl":
                 # one process per GPU: the library's own RCCL communicator (C1), built on first use
                 if self._comm is None:
                     self._comm = ops.Communicator(self.group)
-                self._comm.all_reduce_(A1)
-                self._comm.all_reduce_(Cs)
+                self._comm.all_reduce_(buf)
             else:  # ranks that share a card or run without one (gloo rehearsal): RCCL cannot span them
-                torch.distributed.all_reduce(A1, group=self.group)
-                torch.distributed.all_reduce(Cs, group=self.group)
-        A2 = fp.A.reshape(fp.P, fp.K).contiguous()
-        Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(fp.P, fp.K).contiguous()
+                torch.distributed.all_reduce(buf, group=self.group)
+        if ev:
+            ev[2].record()
+        A2 = fp.A.reshape(P, K).contiguous()
+        Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(P, K).contiguous()
         ops.mu_spatial(A2, A1, Cs, Dd, gamma)
-        fp.A = A2.view(*fp.sz_list, fp.K)
+        fp.A = A2.view(*fp.sz_list, K)
+        fp.invalidate_layouts()   # K6 wrote through the raw pointer: the packed copies are stale
+        if ev:
+            ev[3].record()
+            torch.cuda.synchronize()
+            self.last_spatial_ms = tuple(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
         return fp.A
 
     # ---- fit steps -------------------------------------------------------------------------------------
@@ -365,7 +399,7 @@ class DeformableNMF:
 
         Returns ``(A_t, Y_i, Y)`` like the reference when the dense float64 ``A_t`` fits
         ``DENSE_RETURN_LIMIT`` (or ``return_dense=True``); otherwise ``(None, None, None)``.
-        ``Y_i`` comes from the exhaustive nearest-neighbour search K7 (volumes up to 2^20 voxels, zeros beyond).
+        ``Y_i`` comes from the nearest-neighbour search K7 (``dnmf_image_iwarp``).
         ``gamma_a`` is unused, as in the reference (its footprint update is commented out, :174)."""
         fp = self.fp
         K, P = fp.K, fp.P
@@ -396,11 +430,10 @@ class DeformableNMF:
                 a, _ = ops.warp_gather(fp.A.contiguous(), fp.beta.detach(), order[s:s + step], want_grid=False)
                 A_t[..., s:s + step] = a.permute(2, 3, 4, 1, 0).double().cpu().numpy()
             Yv = frames.view(T_loc, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
-            Yi = np.zeros_like(Yv)
-            if P <= (1 << 20):
-                for s in range(0, T_loc, 256):
-                    yi = ops.image_iwarp(frames, order[s:s + 256], fp.sz_list, fp.beta.detach(), order[s:s + 256])
-                    Yi[..., s:s + 256] = yi.view(-1, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
+            Yi = np.empty_like(Yv)
+            for s in range(0, T_loc, 256):
+                yi = ops.image_iwarp(frames, order[s:s + 256], fp.sz_list, fp.beta.detach(), order[s:s + 256])
+                Yi[..., s:s + 256] = yi.view(-1, X, Y_, Z).permute(1, 2, 3, 0).double().cpu().numpy()
             return A_t, Yi, Yv
 
     def _lists_layout_for_fused_update(self, gamma_c):
@@ -433,8 +466,25 @@ class DeformableNMF:
         model; MultiChannelDNMF lists its colour channels here."""
         return [(self.fp, None)]
 
+    def _note_once(self, key, text):
+        """One line on stdout the first time ``key`` comes up (kernel choices that cost a factor and would otherwise
+        go unnoticed)."""
+        if key not in self._warned:
+            self._warned.add(key)
+            print("[dnmf_amd] " + text, flush=True)
+
     def _gram_rhs_one(self, fp, frames, order):
         """K3, K3s or K3n on the footprints of ``fp``."""
+        if self.gram_kernel == 'auto':
+            if fp.K > 256:
+                self._note_once("k3n-K", f"gram_kernel='auto': K={fp.K} > 256, the neuron-list kernel K3n does not "
+                                "apply; using K3s / K3 by pairs of neuron groups (several times slower)")
+            else:
+                ly = fp.packed_lists()
+                if ly["nslot"] > ops.LISTS_MAX_SLOTS or ly["boxfrac"] >= LISTS_BOXFRAC_LIMIT:
+                    self._note_once("k3n-shape", f"gram_kernel='auto': footprints too wide for the neuron-list kernel K3n "
+                                    f"(pattern slots {ly['nslot']} vs limit {ops.LISTS_MAX_SLOTS}, mean boxes per voxel "
+                                    f"{ly['boxfrac']:.2f} vs limit {LISTS_BOXFRAC_LIMIT}); using K3s / K3 (6-40x slower)")
         if self.gram_kernel in ('auto', 'lists') and fp.K <= 256:
             ly = fp.packed_lists()
             # K3n pays per (voxel, listed neuron) and per listed pair: it wins while a voxel lies in few boxes
@@ -493,7 +543,7 @@ class DeformableNMF:
         update_motion); None when they do not fit ``RECON_CACHE_LIMIT``."""
         chans = self._channels()
         fp0 = chans[0][0]
-        lds = (fp0.P + 3) // 4 * 4
+        lds = ops.halo_voxels(fp0.sz_list)
         if 4 * lds * fp0.T * len(chans) > RECON_CACHE_LIMIT:
             return None
         C = self.C.to(device, torch.float32).contiguous()
@@ -515,8 +565,22 @@ class DeformableNMF:
         ``ops.warp_recon_grad`` with the losses summed over channels."""
         chans = self._channels()
         nc = len(chans)
-        if nc > 1 and norm == 0:
+        if (nc > 1 or times.numel() > K2_MAX_FRAMES) and norm == 0:
             norm = times.numel()
+        if times.numel() > K2_MAX_FRAMES:
+            # frames ride on gridDim.y (<= 65535): larger sets go in pieces; grad accumulates, columns are independent
+            total = None
+            for s in range(0, times.numel(), K2_MAX_FRAMES):
+                e = s + K2_MAX_FRAMES
+                out = self._k2(S_all, Cdev, frames if frame_ids is not None else frames[s:e],
+                               None if frame_ids is None else frame_ids[s:e], times[s:e], grad, norm, want)
+                if total is None:
+                    total = out
+                elif want:
+                    total["loss"] = total["loss"] + out["loss"]
+                    total["frame_loss"] = torch.cat((total["frame_loss"], out["frame_loss"]))
+                    total["reg"] = torch.cat((total["reg"], out["reg"]))
+            return total
         total = None
         for c, (fp, cols) in enumerate(chans):
             if S_all is not None:

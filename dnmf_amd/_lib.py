@@ -8,8 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdnmf_hip.so")
-ABI_VERSION = 1
+# DNMF_LIB selects another build of the library (kernel-variant timing, ablations); the product default is in-tree
+LIB_PATH = os.environ.get("DNMF_LIB") or os.path.join(_HERE, "libdnmf_hip.so")
+ABI_VERSION = 2
 
 _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 
@@ -20,7 +21,9 @@ SIGNATURES = {
     "dnmf_padded_k": (_i, [_i]),
     "dnmf_pack_footprints": (_i, [_vp, _l, _i, _vp, _i, _vp]),
     "dnmf_warp_gather": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
-    "dnmf_recon_image": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
+    "dnmf_halo_voxels": (_l, [_i, _i, _i]),
+    "dnmf_halo_row": (_i, [_i, _i]),
+    "dnmf_recon_image": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dnmf_warp_recon_grad_workspace": (_sz, [_i, _i, _i, _i]),
     "dnmf_warp_recon_grad": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _sz, _vp]),
@@ -44,14 +47,16 @@ SIGNATURES = {
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
     "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),
-    "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp]),
+    "dnmf_image_iwarp_workspace": (_sz, [_i, _i, _i, _i]),
+    "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _sz, _i, _vp, _vp]),
     "dnmf_adam_epoch_workspace": (_sz, [_i]),
     "dnmf_adam_epoch": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _d, _d, _d, _d, _i, _vp, _sz, _vp]),
     "dnmf_render_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _l, _vp]),
-    "dnmf_pack_footprints_lists": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "dnmf_warp_gram_rhs_lists_workspace": (_sz, [_i, _i]),
-    "dnmf_warp_gram_rhs_lists": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp,
-                                      _sz, _vp, _vp]),
+    "dnmf_lists_axis_masks_bytes": (_sz, [_i, _i, _i, _i]),
+    "dnmf_pack_footprints_lists": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dnmf_warp_gram_rhs_lists_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "dnmf_warp_gram_rhs_lists": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp,
+                                      _vp, _sz, _vp, _vp]),
     "dnmf_recon_image_lists": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dnmf_comm_unique_id": (_i, [_vp]),
     "dnmf_comm_init": (_i, [_vp, _vp, _i, _i]),

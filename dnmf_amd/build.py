@@ -1,6 +1,8 @@
 """Build libdnmf_hip.so (gfx950) in-tree with hipcc.
 
-    python -m dnmf_amd.build [--force]
+    python -m dnmf_amd.build [--force] [--out PATH] [-DNAME=VALUE ...]
+
+``--out`` / ``-D``: a kernel-variant build beside the product library (timing studies; ``DNMF_LIB=PATH`` selects it).
 
 hipcc cross-compiles without a GPU.  The library links only against the HIP runtime; torch is not
 involved.  ``-ffp-contract=off``: the coordinate round trip of the warp must not be contracted into FMAs
@@ -29,18 +31,28 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source into ``dnmf_amd/libdnmf_hip.so``; returns its path."""
-    if not force and not _stale():
+# what the last build_library() call did: "compiled" or "reused" (the library was newer than every source)
+LAST_ACTION = None
+
+
+def build_library(force: bool = False, verbose: bool = True, out: str | None = None, defines=()) -> str:
+    """Compile every HIP source into ``dnmf_amd/libdnmf_hip.so`` (or ``out``); returns its path."""
+    global LAST_ACTION
+    target = out or LIB
+    if out is None and not force and not _stale():
+        LAST_ACTION = "reused"
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB, "-ldl"]
+    os.makedirs(os.path.dirname(os.path.abspath(target)), exist_ok=True)
+    cmd = [hipcc, *FLAGS, *defines, *[os.path.join(CSRC, s) for s in SOURCES], "-o", target, "-ldl"]
     if verbose:
         print("[dnmf_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    LAST_ACTION = "compiled"
+    return target
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB)
+    args = sys.argv[1:]
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    print(build_library(force="--force" in args, out=out, defines=[a for a in args if a.startswith("-D")]))

@@ -27,6 +27,7 @@ struct Volume {
     float sx1, sy1, sz1;  // (S-1) as fp32, the divisor of Demix/dNMF.py:55 (sz is int64 there)
     float rcp_yz, rcp_z;  // 1/(Y*Z), 1/Z for the voxel-index split
     float rx1, ry1, rz1;  // RN(1/(S-1)) for the division shortcut of normalise_fast
+    float hx1, hy1, hz1;  // (S-1)/2 (exact) for unnormalise
     int fastdiv;          // every divided axis has 1 <= S-1 <= 65535: the shortcut is exact (tools/check_fastdiv.c)
 };
 
@@ -37,6 +38,7 @@ inline Volume make_volume(int X, int Y, int Z) {
     v.sx1 = (float)(X - 1), v.sy1 = (float)(Y - 1), v.sz1 = (float)(Z - 1);
     v.rcp_yz = 1.0f / ((float)Y * (float)Z), v.rcp_z = 1.0f / (float)Z;
     v.rx1 = X > 1 ? 1.0f / v.sx1 : 0.0f, v.ry1 = Y > 1 ? 1.0f / v.sy1 : 0.0f, v.rz1 = Z > 1 ? 1.0f / v.sz1 : 0.0f;
+    v.hx1 = 0.5f * v.sx1, v.hy1 = 0.5f * v.sy1, v.hz1 = 0.5f * v.sz1;
     v.fastdiv = X > 1 && X <= 65536 && Y > 1 && Y <= 65536 && Z <= 65536;  // Z == 1: z is never divided
     return v;
 }
@@ -48,32 +50,34 @@ struct Sample {
     float wx0, wx1, wy0, wy1, wz0, wz1;  // weight of corner 0 / corner 1 along each axis
 };
 
-// q_d = sum_a basis_a(x,y,z) * beta[a][d]; basis order [1,x,y,z,x^2,y^2,z^2,xy,xz,yz]
-// (Demix/dNMF.py:46-51,54).  `b` points at 30 floats laid out [a*3 + d].
-__device__ __forceinline__ float poly_q(const float *b, int d, float x, float y, float z) {
-    float q = b[0 + d];
-    q = fmaf(b[3 + d], x, q);
-    q = fmaf(b[6 + d], y, q);
-    q = fmaf(b[9 + d], z, q);
-    q = fmaf(b[12 + d], __fmul_rn(x, x), q);
-    q = fmaf(b[15 + d], __fmul_rn(y, y), q);
-    q = fmaf(b[18 + d], __fmul_rn(z, z), q);
-    q = fmaf(b[21 + d], __fmul_rn(x, y), q);
-    q = fmaf(b[24 + d], __fmul_rn(x, z), q);
-    q = fmaf(b[27 + d], __fmul_rn(y, z), q);
-    return q;
+// The warped coordinate q_d = sum_a basis_a(x,y,z) * beta[a][d], basis order [1,x,y,z,x^2,y^2,z^2,xy,xz,yz]
+// (Demix/dNMF.py:46-51,54), evaluated grouped by powers of x:
+//   a_d(x) = 2 q_d = c[0] + c[1] x + c[2] x^2,   c[0] = 2 (b0 + b2 y + b5 y^2 [+ b3 z + b6 z^2 + b9 yz]),
+//                                               c[1] = 2 (b1 + b7 y [+ b8 z]),   c[2] = 2 b4
+// so that a thread that walks along x with (y,z) fixed pays two FMAs per coordinate and voxel.  The reference forms
+// the same polynomial with an fp32 einsum (a BLAS product whose summation order is not specified); any order agrees
+// with it to rounding, and EVERY kernel of this library uses this one, so their coordinates agree bit for bit.  The
+// factor 2 of the normalisation (dNMF.py:55) is folded into the coefficients: scaling by a power of two is exact.
+// At the identity (b1 = e_x, b2 = e_y, b3 = e_z, rest 0) a_d is exactly twice the voxel coordinate (products with
+// an exact 0 or 1 and sums with an exact 0 only), which is what the on-lattice floor() decisions rest on.
+// `b` points at 30 floats laid out [a*3 + d].  HASZ = false is Z == 1 (z = 0: the terms with z are exact zeros).
+template <bool HASZ>
+__device__ __forceinline__ void poly_coeffs(const float *b, int d, float y, float z, float (&c)[3]) {
+    float c0 = fmaf(b[6 + d], y, b[0 + d]);
+    c0 = fmaf(b[15 + d], __fmul_rn(y, y), c0);
+    float c1 = fmaf(b[21 + d], y, b[3 + d]);
+    if (HASZ) {
+        c0 = fmaf(b[9 + d], z, c0);
+        c0 = fmaf(b[18 + d], __fmul_rn(z, z), c0);
+        c0 = fmaf(b[27 + d], __fmul_rn(y, z), c0);
+        c1 = fmaf(b[24 + d], z, c1);
+    }
+    c[0] = __fmul_rn(2.0f, c0), c[1] = __fmul_rn(2.0f, c1), c[2] = __fmul_rn(2.0f, b[12 + d]);
 }
 
-// The same chain for Z == 1 (z = 0): the four terms with z add an exact zero each (finite coefficients), so they are
-// left out; the remaining six keep their order.
-__device__ __forceinline__ float poly_q_xy(const float *b, int d, float x, float y) {
-    float q = b[0 + d];
-    q = fmaf(b[3 + d], x, q);
-    q = fmaf(b[6 + d], y, q);
-    q = fmaf(b[12 + d], __fmul_rn(x, x), q);
-    q = fmaf(b[15 + d], __fmul_rn(y, y), q);
-    q = fmaf(b[21 + d], __fmul_rn(x, y), q);
-    return q;
+// a_d at x; xx = RN(x * x)
+__device__ __forceinline__ float poly_a(const float (&c)[3], float x, float xx) {
+    return fmaf(c[2], xx, fmaf(c[1], x, c[0]));
 }
 
 // clamp into [0, n-1] in one instruction (v_med3_i32)
@@ -83,11 +87,9 @@ __device__ __forceinline__ int clamp_index(int i, int n) {
     return r;
 }
 
-// n = 2q/(S-1) - 1 exactly as the reference evaluates it in fp32 (Demix/dNMF.py:55): IEEE multiply,
-// IEEE divide, IEEE subtract, no contraction.
-__device__ __forceinline__ float normalise(float q, float sm1) {
-    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, q), sm1), 1.0f);
-}
+// n = 2q/(S-1) - 1 exactly as the reference evaluates it in fp32 (Demix/dNMF.py:55): IEEE divide, IEEE subtract,
+// no contraction.  `a` = 2q (poly_a).
+__device__ __forceinline__ float normalise(float a, float sm1) { return __fsub_rn(__fdiv_rn(a, sm1), 1.0f); }
 
 // The same value with the division by the constant S-1 done as a multiplication by r = RN(1/(S-1)) and one
 // correction step: q0 = RN(a r), e = RN(a - q0 (S-1)) (exact), RN(q0 + e r).  For the integer divisors 1..65535 this
@@ -95,29 +97,36 @@ __device__ __forceinline__ float normalise(float q, float sm1) {
 // divisor by tools/check_fastdiv.c; both sequences scale with powers of two, and a quotient too small to be normal
 // rounds to n = -1 either way.  Non-finite a gives a non-finite result in both (inf vs NaN), which every caller
 // turns into zero weights.  Three instructions instead of the ~12 of the IEEE division sequence.
-__device__ __forceinline__ float normalise_fast(float q, float sm1, float rcp) {
-    const float a = __fmul_rn(2.0f, q);
+__device__ __forceinline__ float normalise_fast(float a, float sm1, float rcp) {
     const float q0 = __fmul_rn(a, rcp);
     const float e = __fmaf_rn(-q0, sm1, a);
     return __fsub_rn(__fmaf_rn(e, rcp, q0), 1.0f);
 }
 
-// n along axis d of the volume (0, 1, 2), by the shortcut when the volume allows it.  FAST = 1 / 0: the caller has
-// already branched on vol.fastdiv (kernel variants); -1: wave-uniform choice here.
+// n along axis d of the volume (0, 1, 2) from a = 2q, by the shortcut when the volume allows it.  FAST = 1 / 0: the
+// caller has already branched on vol.fastdiv (kernel variants); -1: wave-uniform choice here.
 template <int FAST = -1>
-__device__ __forceinline__ float normalise_axis(float q, const Volume &vol, int d) {
+__device__ __forceinline__ float normalise_axis(float a, const Volume &vol, int d) {
     const float sm1 = d == 0 ? vol.sx1 : (d == 1 ? vol.sy1 : vol.sz1);
     const float rcp = d == 0 ? vol.rx1 : (d == 1 ? vol.ry1 : vol.rz1);
-    if (FAST == 1) return normalise_fast(q, sm1, rcp);
-    if (FAST == 0) return normalise(q, sm1);
-    return vol.fastdiv ? normalise_fast(q, sm1, rcp) : normalise(q, sm1);
+    if (FAST == 1) return normalise_fast(a, sm1, rcp);
+    if (FAST == 0) return normalise(a, sm1);
+    return vol.fastdiv ? normalise_fast(a, sm1, rcp) : normalise(a, sm1);
 }
 
-// torch grid_sampler_unnormalize, align_corners=True: ((n + 1) / 2) * (S - 1), fp32, no contraction.
-// The round trip normalise -> unnormalise decides floor() for on-lattice points (hard part 1).
-__device__ __forceinline__ float unnormalise(float n, float sm1) {
-    return __fmul_rn(__fmul_rn(__fadd_rn(n, 1.0f), 0.5f), sm1);
+// n of voxel (x,y,z) along axis d, everything from scratch (kernels that do not walk along x)
+template <bool HASZ, int FAST = -1>
+__device__ __forceinline__ float grid_n(const float *b, const Volume &vol, int d, float x, float y, float z) {
+    float c[3];
+    poly_coeffs<HASZ>(b, d, y, z, c);
+    return normalise_axis<FAST>(poly_a(c, x, __fmul_rn(x, x)), vol, d);
 }
+
+// torch grid_sampler_unnormalize, align_corners=True: ((n + 1) / 2) * (S - 1) in fp32 without contraction, as
+// RN(RN(n + 1) * h) with h = (S-1)/2: halving RN(n + 1) is exact (it is 0 or at least 2^-24 in magnitude) and so is
+// halving the integer S-1, so the single rounded product equals the reference's two.  The round trip
+// normalise -> unnormalise decides floor() for on-lattice points (hard part 1).
+__device__ __forceinline__ float unnormalise(float n, float hsm1) { return __fmul_rn(__fadd_rn(n, 1.0f), hsm1); }
 
 __device__ __forceinline__ void axis_weights(float u, int &i0, float &w0, float &w1) {
     const float f = floorf(u);
@@ -135,12 +144,12 @@ template <bool HASZ, int FAST = -1>
 __device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vol, int xi, int yi, int zi) {
     const float x = (float)xi, y = (float)yi, z = HASZ ? (float)zi : 0.0f;
     Sample s;
-    s.ux = unnormalise(normalise_axis<FAST>(HASZ ? poly_q(b, 0, x, y, z) : poly_q_xy(b, 0, x, y), vol, 0), vol.sx1);
-    s.uy = unnormalise(normalise_axis<FAST>(HASZ ? poly_q(b, 1, x, y, z) : poly_q_xy(b, 1, x, y), vol, 1), vol.sy1);
+    s.ux = unnormalise(grid_n<HASZ, FAST>(b, vol, 0, x, y, z), vol.hx1);
+    s.uy = unnormalise(grid_n<HASZ, FAST>(b, vol, 1, x, y, z), vol.hy1);
     axis_weights(s.ux, s.x0, s.wx0, s.wx1);
     axis_weights(s.uy, s.y0, s.wy0, s.wy1);
     if (HASZ) {
-        s.uz = unnormalise(normalise_axis<FAST>(poly_q(b, 2, x, y, z), vol, 2), vol.sz1);
+        s.uz = unnormalise(grid_n<HASZ, FAST>(b, vol, 2, x, y, z), vol.hz1);
         axis_weights(s.uz, s.z0, s.wz0, s.wz1);
     } else {
         s.uz = 0.0f, s.z0 = 0, s.wz0 = 1.0f, s.wz1 = 0.0f;
@@ -150,6 +159,63 @@ __device__ __forceinline__ Sample make_sample_t(const float *b, const Volume &vo
 
 __device__ __forceinline__ Sample make_sample(const float *b, const Volume &vol, int xi, int yi, int zi) {
     return vol.Z > 1 ? make_sample_t<true>(b, vol, xi, yi, zi) : make_sample_t<false>(b, vol, xi, yi, zi);
+}
+
+// ---- halo layout of the gathered single-channel images ------------------------------------------------------
+// The reconstruction images S (K2's source) and the neuron-major footprints At (K3n's source) carry a zero halo of
+// DNMF_HALO voxels around x and y: voxel (x,y,z) lives at (x + HALO) row + (y + HALO) Z + z, where a row holds
+// (Y + 2 HALO) Z floats rounded up to a multiple of 32 -- rows start on 128-byte lines, so the 256-byte runs a wave
+// stores cover whole lines (with rows of 516 floats every run straddled three lines and the stores ran at a third
+// of the rate) -- and there are Xp = X + 2 HALO rows.  A tap cell whose base corner is clamped into [-HALO, S] then never leaves the buffer, and a
+// corner outside the volume reads a zero instead of being masked: `w * 0` is the exact zero the per-corner bounds
+// test of grid_sample yields (its backward skips such corners, i.e. adds zeros too), so neither weight masks nor
+// index clamps nor validity flags are needed along x and y.  z keeps masks and clamps (a halo would triple a
+// two-slice volume).
+constexpr int HALO = DNMF_HALO;
+
+struct HaloLayout {
+    int Xp, Yp;        // rows; voxels of a row along y including the border
+    int rowf;          // floats of a row: Yp * Z rounded up to a multiple of 32 (the excess is zero like the border)
+    long Pp;           // Xp * rowf
+    int row4, col4;    // byte strides of one step in x and in y: rowf*4, Z*4
+    unsigned origin4;  // byte offset of voxel (0,0,0)
+    float xhi, yhi;    // upper clamp of a source coordinate: S + 0.5 (base corner <= S)
+    float row4f, col4f, origin4f;  // the strides and the origin as floats
+    int f32off;        // an image has fewer than 2^24 bytes: tap offsets are exact in fp32 arithmetic
+};
+
+inline HaloLayout make_halo_layout(int X, int Y, int Z) {
+    HaloLayout h;
+    h.Xp = X + 2 * HALO, h.Yp = Y + 2 * HALO;
+    h.rowf = (h.Yp * Z + 31) / 32 * 32;
+    h.Pp = (long)h.Xp * h.rowf;
+    h.row4 = h.rowf * 4, h.col4 = Z * 4;
+    h.origin4 = (unsigned)(((long)HALO * h.rowf + (long)HALO * Z) * 4);
+    h.xhi = (float)X + 0.5f, h.yhi = (float)Y + 0.5f;
+    h.row4f = (float)h.row4, h.col4f = (float)h.col4, h.origin4f = (float)h.origin4;
+    h.f32off = h.Pp * 4 < (1L << 24);
+    return h;
+}
+
+// One axis of a gather from a halo layout: source coordinate u -> base corner f (an integer in [-HALO, S], kept as a
+// float) and the weights of corner f / f + 1 exactly as axis_weights forms them; a coordinate beyond the halo (or
+// NaN: v_med3_f32 then returns the smallest operand) is pulled onto it, where both corners read zeros, so its
+// weights do not matter as long as they are finite.
+__device__ __forceinline__ void axis_taps_halo(float u, float hi, float &f, float &w0, float &w1) {
+    const float uc = __builtin_amdgcn_fmed3f(u, -(float)HALO, hi);
+    f = floorf(uc);
+    w1 = __fsub_rn(uc, f);
+    w0 = __fsub_rn(__fadd_rn(f, 1.0f), uc);
+}
+
+// Byte offset of base corner (fx, fy) from `origin` (the offset of voxel (0,0,z)).  F32OFF: two FMAs and one
+// conversion, exact because every intermediate is an integer below 2^24 (HaloLayout::f32off); else integer
+// conversions and 24-bit multiplies.  (On gfx950 conversions, 24-bit multiplies, v_med3 and DPP operations issue at
+// half the rate of fp32 adds / multiplies / FMAs -- tools/valu_probe.hip.)
+template <bool F32OFF>
+__device__ __forceinline__ unsigned halo_offset(float fx, float fy, const HaloLayout &h, unsigned origin, float originf) {
+    if (F32OFF) return (unsigned)fmaf(fx, h.row4f, fmaf(fy, h.col4f, originf));
+    return (unsigned)(__mul24((int)fx, h.row4) + __mul24((int)fy, h.col4)) + origin;
 }
 
 __device__ __forceinline__ bool in_range(int i, int n) { return (unsigned)i < (unsigned)n; }

@@ -19,7 +19,8 @@ template <int NB, int NF>
 __global__ __launch_bounds__(256) void recon_image_kernel(const float *__restrict__ Apk, long P, int K, int Kp,
                                                           const float *__restrict__ C, long ldc,
                                                           const int *__restrict__ times, int B,
-                                                          float *__restrict__ S, long lds, int groups_per_wave) {
+                                                          float *__restrict__ S, long lds, int groups_per_wave,
+                                                          Volume vol, HaloLayout hl) {
     constexpr int KQ = 4 * NB;  // channels per k-slot
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -77,22 +78,41 @@ __global__ __launch_bounds__(256) void recon_image_kernel(const float *__restric
         for (int nf = 0; nf < NF; ++nf) {
             const int f = f0 + 16 * nf + vi;
             if (f < B) {
-                float *dst = S + (long)f * lds + p0 + 4 * q;
-                if (p0 + 4 * q + 3 < P) {
-                    *reinterpret_cast<f32x4 *>(dst) = acc[nf];
-                } else {
+                // halo layout: voxel (x, y, z) lands at (x + HALO) rowf + (y + HALO) Z + z
+                float *dst = S + (long)f * lds;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (p0 + 4 * q + r < P) dst[r] = acc[nf][r];
+                for (int r = 0; r < 4; ++r) {
+                    const long pr = p0 + 4 * q + r;
+                    if (pr < P) {
+                        int x, y, z;
+                        voxel_xyz(pr, vol, x, y, z);
+                        dst[(long)(x + HALO) * hl.rowf + (long)(y + HALO) * vol.Z + z] = acc[nf][r];
+                    }
                 }
             }
         }
     }
 }
 
+// zero border of B halo-layout images: the first and last HALO rows whole; of the other rows the HALO columns in front
+// and everything behind the volume (HALO columns and the alignment excess)
+__global__ __launch_bounds__(256) void halo_zero_kernel(float *__restrict__ S, long lds, int X, int Y, int Z, int rowf) {
+    const long front = (long)HALO * Z, back = rowf - (long)(HALO + Y) * Z, edge = front + back;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    float *dst = S + (long)blockIdx.y * lds;
+    if (j < 2L * HALO * rowf) {
+        const long row = j / rowf, off = j - row * rowf;
+        dst[(row < HALO ? row : X + row) * rowf + off] = 0.0f;
+    } else if (j < 2L * HALO * rowf + (long)X * edge) {
+        const long jj = j - 2L * HALO * rowf, x = jj / edge, e = jj - x * edge;
+        dst[(x + HALO) * rowf + (e < front ? e : rowf - edge + e)] = 0.0f;
+    }
+}
+
 template <int NB>
-static int launch_recon(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times, int B,
-                        float *S, long lds, hipStream_t stream) {
+static int launch_recon(const float *Apk, const Volume &vol, const HaloLayout &hl, int K, int Kp, const float *C, long ldc,
+                        const int *times, int B, float *S, long lds, hipStream_t stream) {
+    const long P = vol.P;
     const long ngroups = (P + 15) / 16;
     if (B > 16) {
         constexpr int NF = 4;
@@ -100,37 +120,41 @@ static int launch_recon(const float *Apk, long P, int K, int Kp, const float *C,
         const int gpw = 64;
         const long nwg = (ngroups + 4L * gpw - 1) / (4L * gpw);
         hipLaunchKernelGGL((recon_image_kernel<NB, NF>), dim3((unsigned)nwg, (unsigned)fblocks), dim3(256), 0, stream,
-                           Apk, P, K, Kp, C, ldc, times, B, S, lds, gpw);
+                           Apk, P, K, Kp, C, ldc, times, B, S, lds, gpw, vol, hl);
     } else {
         const int gpw = 16;
         const long nwg = (ngroups + 4L * gpw - 1) / (4L * gpw);
         hipLaunchKernelGGL((recon_image_kernel<NB, 1>), dim3((unsigned)nwg, 1u), dim3(256), 0, stream, Apk, P, K, Kp,
-                           C, ldc, times, B, S, lds, gpw);
+                           C, ldc, times, B, S, lds, gpw, vol, hl);
     }
     return check_launch("dnmf_recon_image");
 }
 
 }  // namespace dnmf
 
-extern "C" int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times,
-                                int B, float *S, long lds, dnmf_stream_t stream) {
+extern "C" int dnmf_recon_image(const float *Apk, int X, int Y, int Z, int K, int Kp, const float *C, long ldc,
+                                const int *times, int B, float *S, long lds, dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(Apk && C && times && S, DNMF_E_NULL, "dnmf_recon_image: NULL buffer");
-    DNMF_REQUIRE(P > 0 && K > 0 && B > 0 && Kp == dnmf_padded_k(K) && ldc > 0 && lds >= P && lds % 4 == 0,
-                 DNMF_E_SHAPE, "dnmf_recon_image: P=%ld K=%d Kp=%d B=%d ldc=%ld lds=%ld (lds must be >= P and a multiple of 4)",
-                 P, K, Kp, B, ldc, lds);
-    DNMF_REQUIRE((reinterpret_cast<size_t>(S) & 15) == 0 && (reinterpret_cast<size_t>(Apk) & 15) == 0, DNMF_E_SHAPE,
-                 "dnmf_recon_image: S and Apk must be 16-byte aligned");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && B > 0 && B <= 65535 && Kp == dnmf_padded_k(K) && ldc > 0, DNMF_E_SHAPE,
+                 "dnmf_recon_image: X=%d Y=%d Z=%d K=%d Kp=%d B=%d ldc=%ld", X, Y, Z, K, Kp, B, ldc);
+    const Volume vol = make_volume(X, Y, Z);
+    const HaloLayout hl = make_halo_layout(X, Y, Z);
+    DNMF_REQUIRE(lds >= hl.Pp, DNMF_E_SHAPE, "dnmf_recon_image: lds=%ld < %ld floats of a halo-layout image", lds, hl.Pp);
+    DNMF_REQUIRE((reinterpret_cast<size_t>(Apk) & 15) == 0, DNMF_E_SHAPE, "dnmf_recon_image: Apk must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const long nborder = hl.Pp - vol.P;
+    hipLaunchKernelGGL(halo_zero_kernel, dim3((unsigned)((nborder + 255) / 256), (unsigned)B), dim3(256), 0, st, S, lds, X, Y,
+                       Z, hl.rowf);
     switch (Kp / 16) {
-        case 1: return launch_recon<1>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 2: return launch_recon<2>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 3: return launch_recon<3>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 4: return launch_recon<4>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 5: return launch_recon<5>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 6: return launch_recon<6>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 7: return launch_recon<7>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
-        case 8: return launch_recon<8>(Apk, P, K, Kp, C, ldc, times, B, S, lds, st);
+        case 1: return launch_recon<1>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 2: return launch_recon<2>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 3: return launch_recon<3>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 4: return launch_recon<4>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 5: return launch_recon<5>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 6: return launch_recon<6>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 7: return launch_recon<7>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
+        case 8: return launch_recon<8>(Apk, vol, hl, K, Kp, C, ldc, times, B, S, lds, st);
         default:
             return fail(DNMF_E_UNSUPPORTED, "dnmf_recon_image: K=%d needs Kp=%d > 128 (not built yet)", K, Kp);
     }

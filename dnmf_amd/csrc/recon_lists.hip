@@ -1,5 +1,6 @@
-// Reconstruction image S[b,p] = sum_k C[k,t_b] A[p,k] for COMPACT footprints, from the neuron-major copy At (K,P)
-// and the boxes of dnmf_pack_footprints_lists.
+// Reconstruction image S[b,p] = sum_k C[k,t_b] A[p,k] for COMPACT footprints, from the neuron-major copy At and the
+// boxes of dnmf_pack_footprints_lists.  At and S are both in the halo layout of common.hpp; the kernel sweeps the
+// whole padded image, so the border of S is rewritten (as the zeros the border of At holds) by every call.
 //
 // Same role as recon_image.hip (the reference's einsum of Demix/dNMF.py:58, taken before the warp because the
 // gather is linear).  A tile of 4 x 64 voxels (64 lanes along the contiguous axis, so a wave stores 256-byte runs)
@@ -17,7 +18,7 @@ constexpr int RL_NG = 8;  // neurons held in registers at a time
 
 template <int NW>
 __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restrict__ At, const int *__restrict__ bbox,
-                                                          int K, Volume vol, const float *__restrict__ C, long ldc,
+                                                          int K, Volume vol, HaloLayout hl, const float *__restrict__ C, long ldc,
                                                           const int *__restrict__ times, int B, float *__restrict__ S,
                                                           long lds, int nu, int frames_per_wave) {
     __shared__ int s_list[4][64 * NW];
@@ -27,14 +28,14 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
     const int b0 = (blockIdx.y * 4 + wave) * frames_per_wave;
     if (b0 >= B) return;                               // whole wave leaves; no workgroup barrier below
     const int b1 = min(b0 + frames_per_wave, B);
-    const int YZ = vol.Y * vol.Z;
+    const int YZ = hl.rowf;                            // one padded row (a multiple of 32 floats)
     const int qu = tile % nu, qx = tile / nu;
-    const int u = 64 * qu + lane;                      // position in the (y,z) plane
+    const int u = 64 * qu + lane;                      // position in the padded (y,z) plane
     const bool uin = u < YZ;
-    const int x0 = 4 * qx;
-    // box of the tile
-    const int ylo = (64 * qu) / vol.Z, yhi = min(64 * qu + 63, YZ - 1) / vol.Z;
-    const int xlo = x0, xhi = min(x0 + 3, vol.X - 1);
+    const int x0 = 4 * qx;                             // padded row
+    // box of the tile in volume coordinates
+    const int ylo = (64 * qu) / vol.Z - HALO, yhi = min(64 * qu + 63, hl.Yp * vol.Z - 1) / vol.Z - HALO;
+    const int xlo = x0 - HALO, xhi = min(x0 + 3, hl.Xp - 1) - HALO;
 
     int *lst = s_list[wave];
     int n = 0;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
         for (int b = b0; b < b1; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (uin && x0 + v < vol.X) out[(long)b * lds + (long)v * YZ] = 0.0f;
+                if (uin && x0 + v < hl.Xp) out[(long)b * lds + (long)v * YZ] = 0.0f;
         return;
     }
     for (int g = 0; g < n; g += RL_NG) {
@@ -74,10 +75,10 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
 #pragma unroll
             for (int v = 0; v < 4; ++v) a[i][v] = 0.0f;
             if (ks[i] >= 0) {
-                const float *__restrict__ Ak = At + (long)ks[i] * vol.P + (long)x0 * YZ + u;
+                const float *__restrict__ Ak = At + (long)ks[i] * hl.Pp + (long)x0 * YZ + u;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (uin && x0 + v < vol.X) a[i][v] = Ak[(long)v * YZ];
+                    if (uin && x0 + v < hl.Xp) a[i][v] = Ak[(long)v * YZ];
             }
         }
         // frames in runs of 64: lane j fetches the traces of frame bb + j, the run then reads them as scalars
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
                 if (g > 0) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
-                        if (uin && x0 + v < vol.X) s[v] = dst[(long)v * YZ];
+                        if (uin && x0 + v < hl.Xp) s[v] = dst[(long)v * YZ];
                 }
 #pragma unroll
                 for (int i = 0; i < RL_NG; ++i) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (uin && x0 + v < vol.X) dst[(long)v * YZ] = s[v];
+                    if (uin && x0 + v < hl.Xp) dst[(long)v * YZ] = s[v];
             }
         }
     }
@@ -122,9 +123,10 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
                  X, Y, Z, K, B);
     DNMF_REQUIRE(K <= 256, DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: K=%d > 256", K);
     const Volume vol = make_volume(X, Y, Z);
-    DNMF_REQUIRE(lds >= vol.P, DNMF_E_SHAPE, "dnmf_recon_image_lists: lds=%ld < P=%ld", lds, vol.P);
-    const int nu = (int)(((long)Y * Z + 63) / 64);
-    const long ntile = (long)((X + 3) / 4) * nu;
+    const HaloLayout hl = make_halo_layout(X, Y, Z);
+    DNMF_REQUIRE(lds >= hl.Pp, DNMF_E_SHAPE, "dnmf_recon_image_lists: lds=%ld < %ld floats of a halo-layout image", lds, hl.Pp);
+    const int nu = (hl.rowf + 63) / 64;
+    const long ntile = (long)((hl.Xp + 3) / 4) * nu;
     DNMF_REQUIRE(ntile < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: %ld tiles", ntile);
     // frames per wave: enough waves to fill the chip (>= 16k), long enough runs to amortise the footprint loads
     int fpw = (int)(((long)B * ntile + 16383) / 16384);
@@ -135,11 +137,11 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ntile, (unsigned)ny);
     if (K <= 64)
-        hipLaunchKernelGGL(recon_lists_kernel<1>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<1>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
     else if (K <= 128)
-        hipLaunchKernelGGL(recon_lists_kernel<2>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<2>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
     else
-        hipLaunchKernelGGL(recon_lists_kernel<4>, grid, dim3(256), 0, st, At, bbox, K, vol, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<4>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
     return check_launch("dnmf_recon_image_lists");
 }
 

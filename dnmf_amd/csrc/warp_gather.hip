@@ -21,9 +21,10 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const float *__restric
     voxel_xyz(p, vol, x, y, z);
     const float xf = (float)x, yf = (float)y, zf = (float)z;
     if (grid) {
-        grid[(p * 3 + 0) * B + b] = normalise_axis(poly_q(bt, 0, xf, yf, zf), vol, 0);
-        grid[(p * 3 + 1) * B + b] = normalise_axis(poly_q(bt, 1, xf, yf, zf), vol, 1);
-        grid[(p * 3 + 2) * B + b] = vol.Z > 1 ? normalise_axis(poly_q(bt, 2, xf, yf, zf), vol, 2) : -1.0f;
+        const bool hz = vol.Z > 1;
+        grid[(p * 3 + 0) * B + b] = hz ? grid_n<true>(bt, vol, 0, xf, yf, zf) : grid_n<false>(bt, vol, 0, xf, yf, 0.0f);
+        grid[(p * 3 + 1) * B + b] = hz ? grid_n<true>(bt, vol, 1, xf, yf, zf) : grid_n<false>(bt, vol, 1, xf, yf, 0.0f);
+        grid[(p * 3 + 2) * B + b] = hz ? grid_n<true>(bt, vol, 2, xf, yf, zf) : -1.0f;
     }
     if (!A_t) return;
     const Sample s = make_sample(bt, vol, x, y, z);

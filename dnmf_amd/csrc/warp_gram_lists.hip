@@ -7,24 +7,30 @@
 // 512x512, K=100 a voxel sees 1.1 non-zero footprints on average and A_t^T A_t has ~2.6 GFLOP of non-zero products
 // per 4000 frames, not 11.6 TFLOP.  K3s skips whole 16-neuron blocks but still evaluates 16x16 products per active
 // block pair on the matrix pipe and spends most of its time on block bookkeeping.  Here nothing is padded to
-// blocks: a wave walks over tiles of 256 voxels, works out which neurons can reach the tile at all and evaluates
+// blocks: a wave walks over tiles of 256 voxels, looks up which neurons can reach the tile at all and evaluates
 // only those, on the vector ALU -- no MFMA: there is no dense operand left to feed it.
 //
 // Exactness.  A product is skipped only when one factor is an exact zero, so every sum equals the dense kernel's
 // up to the order of fp32 additions:
 //   - bbox[k] is the bounding box of the non-zeros of footprint k (dnmf_pack_footprints_lists);
-//   - the taps of a tile's voxels are computed with the reference's fp32 coordinate sequence (common.hpp) FIRST,
-//     and the tile's neuron list is every k whose bbox meets the box [min tap, max tap] of those actual taps;
+//   - a tile's neuron list (lists_tilemask_kernel, one bit per neuron) is every k whose bbox meets a box that
+//     CONTAINS all taps of the tile's voxels: the range of the warped coordinate over the tile by interval
+//     arithmetic on the ten monomials, widened by a margin far above the fp32 rounding of either evaluation.  A
+//     neuron listed without need contributes exact zeros (its footprint is zero outside its bbox);
 //   - G[k,l] can be non-zero for some warp only if a 2x2(x2) tap cell meets both bboxes, i.e. if per axis
 //     k_lo - 1 <= l_hi and l_lo - 1 <= k_hi: a static pattern, independent of the warp (both footprints move
 //     under the same map).  Pairs outside the pattern are never accumulated and come out as 0.
 //
-// Data flow.  Lane = voxel (16 lanes along y: the neuron-major footprint copy At (K,P) is read in coalesced 64-byte
-// runs), four voxels per lane.  Per listed neuron: 4 x NTAP loads and FMAs give its warped values a_k at the lane's
-// voxels, then r_k += a_k.y and G_kl += a_k.a_l for the listed l >= k: per-lane partial sums, a fixed DPP tree over
-// the 64 lanes, and one LDS add by the last lane into the wave's private table of pattern slots.  LDS operations of
-// one wave retire in order, so the sum is deterministic.  The table goes to a slab per (frame, chunk); the finish
-// kernel adds the chunks in order and scatters the slots into dense G (K,K), r (K).
+// Data flow.  Lane = voxel (16 lanes along y: the neuron-major footprint copy At is read in coalesced 64-byte
+// runs), four voxels per lane along x; tiles are walked along x, so a lane's (y,z) and with them the coefficients
+// of its coordinate polynomials in x change only at the end of a tile row.  At is in the halo layout of common.hpp:
+// a tap outside the volume reads a zero, no masks or clamps along x and y.  Per listed neuron: 2 x NTAP/2 eight-byte
+// loads and NTAP FMAs per voxel give its warped values a_k, then r_k += a_k.y and G_kl += a_k.a_l for the listed
+// l >= k as per-lane partial sums.  While consecutive tiles have the same list the partial sums stay in registers;
+// when the list changes: a fixed DPP tree over the 64 lanes and one LDS add by the last lane into the wave's private
+// table of pattern slots.  LDS operations of one wave retire in order, so the sum is deterministic.  The table
+// goes to a slab per (frame, chunk); the finish kernel adds the chunks in order and scatters the slots into dense
+// G (K,K), r (K).
 #include <type_traits>
 
 #include "common.hpp"
@@ -36,15 +42,17 @@ constexpr int LISTS_LGV = 2;      // log2 of the voxels per lane (consecutive x 
 constexpr int LISTS_VPL = 1 << LISTS_LGV;
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
 constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items per launch
-constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x (3800 + 256) words of LDS per workgroup
+constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x 3800 words of LDS per workgroup
 
 struct ListParams {
-    const float *At;       // (K,P)
+    const float *At;       // (K, halo layout)
     const int *bbox;       // (K,6) xlo,xhi,ylo,yhi,zlo,zhi; lo > hi for an all-zero footprint
     const int *pair_slot;  // (K,K) symmetric; pairs outside the pattern point at the trash slot nslot-1
+    const unsigned long long *axis_masks;  // per axis and bound the neurons whose box starts / ends there (see below)
     int nslot;             // K rhs slots, then the pattern pairs, then one trash slot
     int K;
     Volume vol;
+    HaloLayout hl;
     const float *beta;
     int T;
     const int *times;
@@ -53,9 +61,10 @@ struct ListParams {
     long ldf;
     const int *frame_ids;
     float *slab;  // (B, nchunks, nslot)
+    unsigned long long *tile_masks;  // (B, ntiles, NW): the neuron list of every tile of every frame
     int nchunks, chunk_len;
     int lgx, lgz;  // tile = (LISTS_VPL << lgx) x 16 x (1 << lgz) voxels, lgx + lgz = 2
-    int nty, ntz, ntiles;
+    int ntx, nty, ntz, ntiles;     // tile q = (qy * ntz + qz) * ntx + qx: walked along x
     unsigned long long *counters;  // optional: [0] += (tile, neuron) evaluations, [1] += (tile, pair) sums
 };
 
@@ -73,28 +82,117 @@ __device__ __forceinline__ float wave_sum_last(float v) {
     return v;
 }
 
-// min / max over the 64 lanes, valid in lane 63
-template <bool MAX>
-__device__ __forceinline__ int wave_minmax_last(int v) {
-    constexpr int ident = MAX ? (int)0x80000000 : 0x7fffffff;
-#define DNMF_STEP(ctrl, rmask)                                                          \
-    {                                                                                   \
-        const int o = __builtin_amdgcn_update_dpp(ident, v, ctrl, rmask, 0xf, false);   \
-        v = MAX ? max(v, o) : min(v, o);                                                \
+// ---- neuron lists of the tiles ---------------------------------------------------------------------------
+// axis_masks: for axis d (0,1,2) two tables of S_d + 2 entries of NW 64-bit words:
+//   LO_d[i + 1] = { k : bbox_lo_d[k] <= i },  i = -1 .. S_d   (entry 0 is the empty set)
+//   HI_d[i]     = { k : bbox_hi_d[k] >= i },  i =  0 .. S_d+1 (the last two are empty)
+// so the neurons whose box meets [a, b] along d are LO_d[min(b, S_d) + 1] & HI_d[max(a, 0)]: the list of a tile is the
+// AND of three such pairs.  Built by lists_axis_masks_kernel from bbox.
+__host__ __device__ inline long axis_masks_offset(const Volume &vol, int d, int hi_table) {
+    const int S[3] = {vol.X, vol.Y, vol.Z};
+    long o = 0;
+    for (int e = 0; e < d; ++e) o += 2L * (S[e] + 2);
+    return o + (hi_table ? S[d] + 2 : 0);
+}
+__host__ __device__ inline long axis_masks_entries(const Volume &vol) { return 2L * (vol.X + vol.Y + vol.Z + 6); }
+
+__global__ __launch_bounds__(256) void lists_axis_masks_kernel(const int *__restrict__ bbox, int K, Volume vol, int NW,
+                                                               unsigned long long *__restrict__ masks) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= axis_masks_entries(vol)) return;
+    const int S[3] = {vol.X, vol.Y, vol.Z};
+    long o = e;
+    int d = 0;
+    while (o >= 2L * (S[d] + 2)) o -= 2L * (S[d] + 2), ++d;
+    const bool hi_table = o >= S[d] + 2;
+    const int i = hi_table ? (int)(o - (S[d] + 2)) : (int)o - 1;
+    for (int w = 0; w < NW; ++w) {
+        unsigned long long m = 0;
+        for (int j = 0; j < 64; ++j) {
+            const int k = 64 * w + j;
+            if (k >= K) break;
+            const int lo = bbox[k * 6 + 2 * d], hi = bbox[k * 6 + 2 * d + 1];
+            const bool in = lo <= hi && (hi_table ? hi >= i : lo <= i);
+            m |= (unsigned long long)in << j;
+        }
+        masks[e * NW + w] = m;
     }
-    DNMF_STEP(0x111, 0xf)
-    DNMF_STEP(0x112, 0xf)
-    DNMF_STEP(0x114, 0xf)
-    DNMF_STEP(0x118, 0xf)
-    DNMF_STEP(0x142, 0xa)
-    DNMF_STEP(0x143, 0xc)
-#undef DNMF_STEP
-    return v;
 }
 
-template <int NTAP, int NW, int FAST>
+// Conservative range of a_d = 2 q_d (poly_coeffs) over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0:
+// every monomial is monotone there, so a term's range follows from the sign of its coefficient.
+__device__ __forceinline__ void poly_range(const float *b, int d, const float (&lo)[3], const float (&hi)[3], bool hasz,
+                                           float &amin, float &amax) {
+    const float mlo[9] = {lo[0], lo[1], lo[2], lo[0] * lo[0], lo[1] * lo[1], lo[2] * lo[2], lo[0] * lo[1], lo[0] * lo[2], lo[1] * lo[2]};
+    const float mhi[9] = {hi[0], hi[1], hi[2], hi[0] * hi[0], hi[1] * hi[1], hi[2] * hi[2], hi[0] * hi[1], hi[0] * hi[2], hi[1] * hi[2]};
+    amin = amax = b[d];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const bool zterm = i == 2 || i == 5 || i == 7 || i == 8;
+        if (zterm && !hasz) continue;
+        const float c = b[3 * (i + 1) + d];
+        const float p = c * mlo[i], q = c * mhi[i];
+        amin += fminf(p, q), amax += fmaxf(p, q);
+    }
+    amin *= 2.0f, amax *= 2.0f;
+}
+
+// One thread per (frame, tile): the tile's neuron list as NW 64-bit words.
+template <int NW>
+__global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)p.B * p.ntiles) return;
+    const int b = (int)(id / p.ntiles), q = (int)(id - (long)b * p.ntiles);
+    const Volume vol = p.vol;
+    const int t = p.times ? p.times[b] : b;
+    float bt[30];
+    load_beta(p.beta, p.T, t, bt);
+    const int qx = q % p.ntx, rest = q / p.ntx, qz = rest % p.ntz, qy = rest / p.ntz;
+    const int tx = LISTS_VPL << p.lgx, tz = 1 << p.lgz;
+    const int S[3] = {vol.X, vol.Y, vol.Z};
+    const int first[3] = {qx * tx, qy * 16, qz * tz}, size[3] = {tx, 16, tz};
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) lo[d] = (float)first[d], hi[d] = (float)min(first[d] + size[d] - 1, S[d] - 1);
+    const bool hasz = vol.Z > 1;
+    unsigned long long m[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m[w] = ~0ull;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int a = 0, c = 0;  // tap range along d; Z == 1: the taps sit in slice 0
+        if (d < 2 || hasz) {
+            float amin, amax;
+            poly_range(bt, d, lo, hi, hasz, amin, amax);
+            const float h = d == 0 ? vol.hx1 : (d == 1 ? vol.hy1 : vol.hz1);
+            // the source coordinate is a non-decreasing function of a; margin: both evaluations round a few times at
+            // magnitudes up to ~2S, i.e. errors of order S * 1e-6 voxels
+            const float margin = 0.0625f + 4e-6f * (float)S[d];
+            const float ulo = unnormalise(normalise_axis<-1>(amin, vol, d), h) - margin;
+            const float uhi = unnormalise(normalise_axis<-1>(amax, vol, d), h) + margin;
+            if (!(ulo <= uhi)) {  // NaN coordinates: every tap of the tile is pulled into the halo and reads zeros
+#pragma unroll
+                for (int w = 0; w < NW; ++w) m[w] = 0;
+                continue;
+            }
+            a = (int)floorf(fminf(fmaxf(ulo, -4.0f), (float)S[d] + 4.0f));
+            c = (int)floorf(fminf(fmaxf(uhi, -4.0f), (float)S[d] + 4.0f)) + 1;
+        }
+        const unsigned long long *LO = p.axis_masks + (axis_masks_offset(vol, d, 0) + (min(c, S[d]) + 1 < 0 ? 0 : min(c, S[d]) + 1)) * NW;
+        const unsigned long long *HI = p.axis_masks + (axis_masks_offset(vol, d, 1) + min(max(a, 0), S[d] + 1)) * NW;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m[w] &= LO[w] & HI[w];
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) p.tile_masks[id * NW + w] = m[w];
+}
+
+template <int NTAP, int NW, int FAST, bool F32OFF>
 __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     extern __shared__ float s_tab[];
+    constexpr bool HASZ = NTAP == 8;
+    constexpr int ND = HASZ ? 3 : 2;
+    constexpr int NPAIR = LISTS_NG * (LISTS_NG + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long item = (long)blockIdx.x * 4 + wave;  // chunk-major: neighbouring waves work on the same part of At
@@ -104,8 +202,9 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     const int t = p.times ? p.times[b] : b;
     const float *__restrict__ yb = p.frames + (long)(p.frame_ids ? p.frame_ids[b] : b) * p.ldf;
     const Volume vol = p.vol;
+    const HaloLayout hl = p.hl;
     const int K = p.K;
-    const size_t plane = (size_t)vol.P * 4u;  // bytes of one neuron's footprint
+    const size_t plane = (size_t)hl.Pp * 4u;  // bytes of one neuron's footprint image
 
     float bt[30];
     load_beta(p.beta, p.T, t, bt);
@@ -113,211 +212,284 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     float *tab = s_tab + (size_t)wave * p.nslot;
     for (int i = lane; i < p.nslot; i += 64) tab[i] = 0.0f;
     const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tab;  // LDS byte address
-    int *lst = reinterpret_cast<int *>(s_tab + (size_t)4 * p.nslot) + wave * (64 * NW);  // this tile's neuron list
-
-    // the neurons this lane tests against a tile's tap box: k = lane + 64 w
-    int bx[NW][6];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int k = lane + 64 * w;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) bx[w][e] = k < K ? p.bbox[k * 6 + e] : ((e & 1) ? -1 : 0x7fffffff);
-    }
 
     const int lgx = p.lgx, lgz = p.lgz;
     const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & 15, lx = lane >> (lgz + 4);
     const int q_begin = chunk * p.chunk_len;
     const int q_end = min(q_begin + p.chunk_len, p.ntiles);
+    const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
     unsigned long long n_eval = 0, n_pair = 0;  // wave-uniform
 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    for (int q = q_begin; q < q_end; ++q) {
-        const int qz = q % p.ntz, qy = (q / p.ntz) % p.nty, qx = q / (p.ntz * p.nty);
-        const int y = (qy << 4) + ly, z = (qz << lgz) + lz;
-
-        // ---- taps of this lane's four voxels ------------------------------------------------------------
-        unsigned off[LISTS_VPL][NTAP];  // byte offset of the tap inside a neuron's plane
-        float w[LISTS_VPL][NTAP];
-        float yv[LISTS_VPL];
-        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    // one lane, one LDS add (an atomic builtin here is rewritten into a cross-lane reduction loop)
+    auto add_slot = [&](int slot, float total_in_last_lane) {
+        const unsigned addr = tab_lds + 4u * (unsigned)slot;
+        if (lane == 63) asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(total_in_last_lane) : "memory");
+    };
+    // slot of a pair: a scalar load issued before the arithmetic that precedes its use
+    auto pair_slot_of = [&](int k, int l) {
+        return __builtin_amdgcn_readfirstlane(p.pair_slot[max(k, 0) * K + max(l, 0)]);
+    };
+    // the lowest LISTS_NG set bits of a list (-1 past its end); `rem` loses them
+    auto take_ids = [&](unsigned long long (&rem)[NW], int (&ks)[LISTS_NG]) {
 #pragma unroll
-        for (int v = 0; v < LISTS_VPL; ++v) {
-            const int x = (qx << (lgx + LISTS_LGV)) + (v << lgx) + lx;
-#pragma unroll
-            for (int c = 0; c < NTAP; ++c) off[v][c] = 0u, w[v][c] = 0.0f;
-            yv[v] = 0.0f;
-            if (x < vol.X && y < vol.Y && z < vol.Z) {
-                const Sample sm = make_sample_t<(NTAP == 8), FAST>(bt, vol, x, y, z);
-                unsigned vox[NTAP];
-                make_taps<NTAP>(sm, vol, w[v], vox);
-#pragma unroll
-                for (int c = 0; c < NTAP; ++c) off[v][c] = vox[c] * 4u;
-                yv[v] = yb[((long)x * vol.Y + y) * vol.Z + z];
-                mn[0] = min(mn[0], sm.x0), mx[0] = max(mx[0], sm.x0);
-                mn[1] = min(mn[1], sm.y0), mx[1] = max(mx[1], sm.y0);
-                if (NTAP == 8) mn[2] = min(mn[2], sm.z0), mx[2] = max(mx[2], sm.z0);
-            }
-        }
-        // box of the (clamped) tap coordinates of the whole tile; an all-invalid lane contributes the identities
-        int lo[3], hi[3];
-#pragma unroll
-        for (int d = 0; d < (NTAP == 8 ? 3 : 2); ++d) {
-            const int size = d == 0 ? vol.X : (d == 1 ? vol.Y : vol.Z);
-            const int a = __builtin_amdgcn_readlane(wave_minmax_last<false>(mn[d]), 63);
-            const int c = __builtin_amdgcn_readlane(wave_minmax_last<true>(mx[d]), 63);
-            lo[d] = min(max(a, 0), size - 1);
-            hi[d] = min(max(c + 1, 0), size - 1);
-        }
-        if (NTAP != 8) lo[2] = 0, hi[2] = 0;
-
-        // ---- the tile's neuron list: ascending neuron indices -------------------------------------------------
-        // Up to LISTS_NG neurons (nearly every tile) are picked out of the ballot masks with scalar bit operations;
-        // longer lists are compacted into the wave's LDS strip.
-        unsigned long long msk[NW];
-        int n = 0;  // wave-uniform
-#pragma unroll
-        for (int wd = 0; wd < NW; ++wd) {
-            const bool hit = bx[wd][0] <= hi[0] && bx[wd][1] >= lo[0] && bx[wd][2] <= hi[1] && bx[wd][3] >= lo[1] &&
-                             bx[wd][4] <= hi[2] && bx[wd][5] >= lo[2];
-            msk[wd] = __ballot(hit);
-            n += __builtin_popcountll(msk[wd]);
-        }
-        if (n == 0) continue;
-        if (n > LISTS_NG) {
-            int at = 0;
+        for (int i = 0; i < LISTS_NG; ++i) {
+            int k = -1;
+            bool found = false;
 #pragma unroll
             for (int wd = 0; wd < NW; ++wd) {
-                const unsigned long long m = msk[wd];
-                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if ((m >> lane) & 1) lst[at + before] = lane + 64 * wd;
-                at += __builtin_popcountll(m);
+                const bool take = !found && rem[wd] != 0;
+                k = take ? 64 * wd + __builtin_ctzll(rem[wd]) : k;
+                rem[wd] = take ? rem[wd] & (rem[wd] - 1) : rem[wd];
+                found = found || take;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            ks[i] = k;
         }
+    };
 
-        // neuron ids of the group that starts at list position g (wave-uniform scalars; -1 past the end)
-        auto group_ids = [&](int g, int (&ks)[LISTS_NG]) {
-            if (n <= LISTS_NG) {  // g == 0: lowest set bits of the masks, in order
-                unsigned long long rem[NW];
-#pragma unroll
-                for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
-#pragma unroll
-                for (int i = 0; i < LISTS_NG; ++i) {
-                    int k = -1;
-                    bool found = false;
-#pragma unroll
-                    for (int wd = 0; wd < NW; ++wd) {
-                        const bool take = !found && rem[wd] != 0;
-                        k = take ? 64 * wd + __builtin_ctzll(rem[wd]) : k;
-                        rem[wd] = take ? rem[wd] & (rem[wd] - 1) : rem[wd];
-                        found = found || take;
-                    }
-                    ks[i] = k;
-                }
-                return;
-            }
-            const int mine = lst[min(g + (lane & 7), n - 1)];
-#pragma unroll
-            for (int i = 0; i < LISTS_NG; ++i) ks[i] = g + i < n ? __builtin_amdgcn_readlane(mine, i) : -1;
-        };
-        auto eval = [&](int k, float (&a)[LISTS_VPL]) {
-            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane;
-#pragma unroll
-            for (int v = 0; v < LISTS_VPL; ++v) {
-                // the offsets are re-materialised as 32-bit values here so that the loads take the
-                // (scalar base + 32-bit vector offset) form; hoisted out of the neuron loop they become 64-bit pairs
-                unsigned o[NTAP];
-#pragma unroll
-                for (int c = 0; c < NTAP; ++c) {
-                    o[c] = off[v][c];
-                    asm("" : "+v"(o[c]));
-                }
-                float s = *reinterpret_cast<const float *>(Ak + o[0]) * w[v][0];
-#pragma unroll
-                for (int c = 1; c < NTAP; ++c) s = fmaf(*reinterpret_cast<const float *>(Ak + o[c]), w[v][c], s);
-                a[v] = s;
-            }
-        };
-        auto dot4 = [&](const float (&a)[LISTS_VPL], const float (&c)[LISTS_VPL]) {
-            float s = a[0] * c[0];
-#pragma unroll
-            for (int v = 1; v < LISTS_VPL; ++v) s = fmaf(a[v], c[v], s);
-            return s;
-        };
-        // one lane, one LDS add (an atomic builtin here is rewritten into a cross-lane reduction loop)
-        auto add_slot = [&](int slot, float total_in_last_lane) {
-            const unsigned addr = tab_lds + 4u * (unsigned)slot;
-            if (lane == 63) asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(total_in_last_lane) : "memory");
-        };
-        // slot of a pair: a scalar load issued before the arithmetic that precedes its use
-        auto pair_slot_of = [&](int k, int l) {
-            return __builtin_amdgcn_readfirstlane(p.pair_slot[max(k, 0) * K + max(l, 0)]);
-        };
-        // the N leading neurons of a group: their warped values, then the sums among themselves and against the frame;
-        // straight-line code, so that the row requests overlap and the N + N(N+1)/2 reduction trees interleave
-        auto within = [&](auto nn, const int (&ks)[LISTS_NG], float (&a)[LISTS_NG][LISTS_VPL]) {
+    // partial sums of the current run of tiles with one and the same list of at most LISTS_NG neurons
+    float acc_r[LISTS_NG], acc_p[NPAIR];
+    int run_k[LISTS_NG];
+    int run_n = 0;  // 0: nothing pending
+    auto flush = [&]() {
+        if (run_n == 0) return;
+        auto go = [&](auto nn) {
             constexpr int N = decltype(nn)::value;
-#pragma unroll
-            for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
             int sl[N][N];
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
-                for (int j = i; j < N; ++j) sl[i][j] = pair_slot_of(ks[i], ks[j]);
+                for (int j = i; j < N; ++j) sl[i][j] = pair_slot_of(run_k[i], run_k[j]);
             float sr[N], sp[N][N];
+            int e = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                sr[i] = wave_sum_last(dot4(a[i], yv));
+                sr[i] = wave_sum_last(acc_r[i]);
 #pragma unroll
-                for (int j = i; j < N; ++j) sp[i][j] = wave_sum_last(dot4(a[i], a[j]));
+                for (int j = i; j < N; ++j) sp[i][j] = wave_sum_last(acc_p[e++]);
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                add_slot(ks[i], sr[i]);
+                add_slot(run_k[i], sr[i]);
 #pragma unroll
                 for (int j = i; j < N; ++j) add_slot(sl[i][j], sp[i][j]);
             }
         };
+        using std::integral_constant;
+        switch (run_n) {
+            case 1: go(integral_constant<int, 1>{}); break;
+            case 2: go(integral_constant<int, 2>{}); break;
+            case 3: go(integral_constant<int, 3>{}); break;
+            default: go(integral_constant<int, 4>{}); break;
+        }
+        static_assert(LISTS_NG == 4, "the dispatch above lists the group sizes");
+        run_n = 0;
+    };
+
+    float c[ND][3];
+    int row_of_c = -1;  // the tile row (qy, qz) the coefficients belong to
+    unsigned long long prev[NW];
+#pragma unroll
+    for (int wd = 0; wd < NW; ++wd) prev[wd] = 0;
+
+    for (int q = q_begin; q < q_end; ++q) {
+        unsigned long long msk[NW];
+        int n = 0;  // wave-uniform
+        bool same = true;
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            msk[wd] = masks[(long)q * NW + wd];
+            msk[wd] = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(msk[wd] >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)msk[wd]);
+            n += __builtin_popcountll(msk[wd]);
+            same = same && msk[wd] == prev[wd];
+        }
+        if (n == 0) continue;
+        if (!same || n > LISTS_NG) flush();
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) prev[wd] = n > LISTS_NG ? 0 : msk[wd];
+
+        const int qx = q % p.ntx, rest = q / p.ntx;
+        if (rest != row_of_c) {
+            const int qz = rest % p.ntz, qy = rest / p.ntz;
+            const float yf = (float)((qy << 4) + ly), zf = (float)((qz << lgz) + lz);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) poly_coeffs<HASZ>(bt, d, yf, zf, c[d]);
+            row_of_c = rest;
+        }
+        const int qz = rest % p.ntz, qy = rest / p.ntz;
+        const int y = (qy << 4) + ly, z = (qz << lgz) + lz;
+        const bool yz_in = y < vol.Y && z < vol.Z;
+
+        // ---- taps of this lane's four voxels: byte offsets of the two x-columns of the tap cell, weights ------------
+        unsigned off[LISTS_VPL][NTAP / 2];   // [.][dx + 2 dz]: the (y, y+1) pair is one eight-byte load
+        float w[LISTS_VPL][NTAP];            // [.][dy + 2 (dx + 2 dz)]
+        float yv[LISTS_VPL];
+        const int xt = qx << (lgx + LISTS_LGV);  // first x of the tile
+        const float x0f = (float)(xt + lx);
+        const bool full = xt + (LISTS_VPL << lgx) <= vol.X && (qy << 4) + 16 <= vol.Y && (qz << lgz) + (1 << lgz) <= vol.Z;
+        // frame values: (scalar base + 32-bit lane offset) loads; the voxels of a lane are (1 << lgx) rows apart
+        const unsigned yo0 = (unsigned)(((xt + lx) * vol.Y + min(y, vol.Y - 1)) * vol.Z + min(z, vol.Z - 1)) * 4u;
+        const unsigned ystep = (unsigned)((vol.Y * vol.Z) << lgx) * 4u;
+        auto taps = [&](auto full_tile) {
+            constexpr bool FULL = decltype(full_tile)::value;
+#pragma unroll
+            for (int v = 0; v < LISTS_VPL; ++v) {
+                const int x = xt + (v << lgx) + lx;
+                const float xf = x0f + (float)(v << lgx), xx = __fmul_rn(xf, xf);
+                float fx, fy, wx[2], wy[2];
+                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[0], xf, xx), vol, 0), vol.hx1), hl.xhi, fx, wx[0],
+                               wx[1]);
+                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[1], xf, xx), vol, 1), vol.hy1), hl.yhi, fy, wy[0],
+                               wy[1]);
+                const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);
+                float wzm[2] = {1.0f, 0.0f};
+                unsigned zo[2] = {0u, 0u};
+                if (HASZ) {
+                    int iz;
+                    float wz[2];
+                    axis_weights(unnormalise(normalise_axis<FAST>(poly_a(c[ND - 1], xf, xx), vol, 2), vol.hz1), iz, wz[0], wz[1]);
+#pragma unroll
+                    for (int dz = 0; dz < 2; ++dz) {
+                        wzm[dz] = in_range(iz + dz, vol.Z) ? wz[dz] : 0.0f;
+                        zo[dz] = (unsigned)clamp_index(iz + dz, vol.Z) * 4u;
+                    }
+                }
+                const bool in = FULL || (yz_in && x < vol.X);   // a voxel beyond the volume: weights 0, frame value 0
+#pragma unroll
+                for (int dz = 0; dz < NTAP / 4; ++dz)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        off[v][dx + 2 * dz] = o0 + zo[dz] + (dx ? (unsigned)hl.row4 : 0u);
+                        const float wxz = HASZ ? __fmul_rn(wx[dx], wzm[dz]) : wx[dx];
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) w[v][dy + 2 * (dx + 2 * dz)] = in ? __fmul_rn(wxz, wy[dy]) : 0.0f;
+                    }
+                unsigned yo = in ? yo0 + (unsigned)v * ystep : 0u;
+                asm("" : "+v"(yo));
+                const float val = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(yb) + yo);
+                yv[v] = in ? val : 0.0f;
+            }
+        };
+        if (full)
+            taps(std::true_type{});
+        else
+            taps(std::false_type{});
+
+        auto eval = [&](int k, float (&a)[LISTS_VPL]) {
+            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane;
+#pragma unroll
+            for (int v = 0; v < LISTS_VPL; ++v) {
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < NTAP / 2; ++e) {
+                    // the offsets are re-materialised as 32-bit values here so that the loads take the
+                    // (scalar base + 32-bit vector offset) form; hoisted out of the neuron loop they become 64-bit pairs
+                    unsigned o = off[v][e];
+                    asm("" : "+v"(o));
+                    const char *src = Ak + o;
+                    const float s0 = *reinterpret_cast<const float *>(src);
+                    const float s1 = *reinterpret_cast<const float *>(src + (HASZ ? hl.col4 : 4));
+                    s = fmaf(s0, w[v][2 * e], s);
+                    s = fmaf(s1, w[v][2 * e + 1], s);
+                }
+                a[v] = s;
+            }
+        };
+        auto dot4 = [&](const float (&a)[LISTS_VPL], const float (&cc)[LISTS_VPL], float init) {
+            float s = init;
+#pragma unroll
+            for (int v = 0; v < LISTS_VPL; ++v) s = fmaf(a[v], cc[v], s);
+            return s;
+        };
 
         n_eval += n, n_pair += n * (n + 1) / 2;
+        if (n <= LISTS_NG) {
+            // the usual case: the whole list in registers; sums join the pending run (same list) or start one
+            unsigned long long rem[NW];
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
+            int ks[LISTS_NG];
+            take_ids(rem, ks);
+            const bool fresh = run_n == 0;
+            auto go = [&](auto nn) {
+                constexpr int N = decltype(nn)::value;
+                float a[N][LISTS_VPL];
+#pragma unroll
+                for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    acc_r[i] = dot4(a[i], yv, fresh ? 0.0f : acc_r[i]);
+#pragma unroll
+                    for (int j = i; j < N; ++j, ++e) acc_p[e] = dot4(a[i], a[j], fresh ? 0.0f : acc_p[e]);
+                }
+            };
+            using std::integral_constant;
+            switch (n) {
+                case 1: go(integral_constant<int, 1>{}); break;
+                case 2: go(integral_constant<int, 2>{}); break;
+                case 3: go(integral_constant<int, 3>{}); break;
+                default: go(integral_constant<int, 4>{}); break;
+            }
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i) run_k[i] = ks[i];
+            run_n = n;
+            continue;
+        }
+        // long lists: groups of LISTS_NG neurons, every group against itself and against every later group; reduced
+        // and added tile by tile
+        unsigned long long rem1[NW];
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) rem1[wd] = msk[wd];
         for (int g1 = 0; g1 < n; g1 += LISTS_NG) {
             int kA[LISTS_NG];
             float aA[LISTS_NG][LISTS_VPL];
-            group_ids(g1, kA);
-            using std::integral_constant;
-            switch (min(n - g1, LISTS_NG)) {
-                case 1: within(integral_constant<int, 1>{}, kA, aA); break;
-                case 2: within(integral_constant<int, 2>{}, kA, aA); break;
-                case 3: within(integral_constant<int, 3>{}, kA, aA); break;
-                default: within(integral_constant<int, 4>{}, kA, aA); break;
+            take_ids(rem1, kA);
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i)
+                if (kA[i] >= 0) {
+                    eval(kA[i], aA[i]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < LISTS_VPL; ++v) aA[i][v] = 0.0f;
+                }
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i) {
+                if (kA[i] < 0) continue;
+                add_slot(kA[i], wave_sum_last(dot4(aA[i], yv, 0.0f)));
+#pragma unroll
+                for (int j = i; j < LISTS_NG; ++j)
+                    if (kA[j] >= 0) add_slot(pair_slot_of(kA[i], kA[j]), wave_sum_last(dot4(aA[i], aA[j], 0.0f)));
             }
-            static_assert(LISTS_NG == 4, "the dispatch above lists the group sizes");
-            // pairs of this (then full) group with every later group
+            unsigned long long rem2[NW];
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rem2[wd] = rem1[wd];
             for (int g2 = g1 + LISTS_NG; g2 < n; g2 += LISTS_NG) {
                 int kB[LISTS_NG];
-                float aB[LISTS_NG][LISTS_VPL];
-                group_ids(g2, kB);
+                take_ids(rem2, kB);
 #pragma unroll
                 for (int j = 0; j < LISTS_NG; ++j) {
                     if (kB[j] < 0) continue;
-                    eval(kB[j], aB[j]);
+                    float aB[LISTS_VPL];
+                    eval(kB[j], aB);
                     int sl[LISTS_NG];
 #pragma unroll
                     for (int i = 0; i < LISTS_NG; ++i) sl[i] = pair_slot_of(kA[i], kB[j]);
                     float sp[LISTS_NG];
 #pragma unroll
-                    for (int i = 0; i < LISTS_NG; ++i) sp[i] = wave_sum_last(dot4(aA[i], aB[j]));
+                    for (int i = 0; i < LISTS_NG; ++i) sp[i] = wave_sum_last(dot4(aA[i], aB, 0.0f));
 #pragma unroll
-                    for (int i = 0; i < LISTS_NG; ++i) add_slot(sl[i], sp[i]);
+                    for (int i = 0; i < LISTS_NG; ++i)
+                        if (kA[i] >= 0) add_slot(sl[i], sp[i]);
                 }
             }
         }
     }
+    flush();
 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -354,9 +526,11 @@ __global__ void lists_init_kernel(int *bbox, int K) {
     if (i < K * 6) bbox[i] = (i & 1) ? -1 : 0x7fffffff;
 }
 
-// At[k][p] = A[p][k] through a 32x32 LDS tile; bbox[k] grows over the non-zeros
+// At[k][halo(p)] = A[p][k] through a 32x32 LDS tile (the border of At is zeroed beforehand); bbox[k] grows over the
+// non-zeros
 __global__ __launch_bounds__(256) void lists_transpose_kernel(const float *__restrict__ A, long P, int K, Volume vol,
-                                                              float *__restrict__ At, int *__restrict__ bbox) {
+                                                              HaloLayout hl, float *__restrict__ At,
+                                                              int *__restrict__ bbox) {
     __shared__ float tile[32][33];
     const long p0 = (long)blockIdx.x * 32;
     const int k0 = blockIdx.y * 32;
@@ -372,10 +546,10 @@ __global__ __launch_bounds__(256) void lists_transpose_kernel(const float *__res
         const long pp = p0 + tx;
         if (k < K && pp < P) {
             const float v = tile[tx][i];
-            At[(long)k * P + pp] = v;
+            int x, y, z;
+            voxel_xyz(pp, vol, x, y, z);
+            At[(long)k * hl.Pp + (long)(x + HALO) * hl.rowf + (long)(y + HALO) * vol.Z + z] = v;
             if (v != 0.0f) {
-                int x, y, z;
-                voxel_xyz(pp, vol, x, y, z);
                 atomicMin(&bbox[k * 6 + 0], x), atomicMax(&bbox[k * 6 + 1], x);
                 atomicMin(&bbox[k * 6 + 2], y), atomicMax(&bbox[k * 6 + 3], y);
                 atomicMin(&bbox[k * 6 + 4], z), atomicMax(&bbox[k * 6 + 5], z);
@@ -426,13 +600,14 @@ __global__ __launch_bounds__(256) void lists_pairs_kernel(const int *__restrict_
     }
 }
 
-static void lists_tile_shape(const Volume &vol, int &lgx, int &lgz, int &nty, int &ntz, int &ntiles) {
+static void lists_tile_shape(const Volume &vol, int &lgx, int &lgz, int &ntx, int &nty, int &ntz, int &ntiles) {
     lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
     lgx = 2 - lgz;
     const int tx = LISTS_VPL << lgx, tz = 1 << lgz;
+    ntx = (vol.X + tx - 1) / tx;
     ntz = (vol.Z + tz - 1) / tz;
     nty = (vol.Y + 15) / 16;
-    ntiles = ((vol.X + tx - 1) / tx) * nty * ntz;
+    ntiles = ntx * nty * ntz;
 }
 
 static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len) {
@@ -444,48 +619,72 @@ static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len)
     nchunks = (ntiles + chunk_len - 1) / chunk_len;
 }
 
+static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
+
 template <int NTAP, int NW>
 static void launch_lists_t(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
-    if (p.vol.fastdiv)
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1>), dim3(nwg), dim3(256), lds, st, p);
+    const long nthreads = (long)p.B * p.ntiles;
+    hipLaunchKernelGGL((lists_tilemask_kernel<NW>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
+    if (p.vol.fastdiv && p.hl.f32off)
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1, true>), dim3(nwg), dim3(256), lds, st, p);
+    else if (p.vol.fastdiv)
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1, false>), dim3(nwg), dim3(256), lds, st, p);
     else
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 0>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 0, false>), dim3(nwg), dim3(256), lds, st, p);
 }
 
 }  // namespace dnmf
 
 extern "C" {
 
+size_t dnmf_lists_axis_masks_bytes(int X, int Y, int Z, int K) {
+    if (X <= 0 || Y <= 0 || Z <= 0 || K <= 0 || K > 64 * dnmf::LISTS_MAXW) return 0;
+    return (size_t)dnmf::axis_masks_entries(dnmf::make_volume(X, Y, Z)) * dnmf::lists_words(K) * sizeof(unsigned long long);
+}
+
 int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float *At, int *bbox, int *pair_slot,
-                               int *nslot, dnmf_stream_t stream) {
+                               int *nslot, void *axis_masks, dnmf_stream_t stream) {
     using namespace dnmf;
-    DNMF_REQUIRE(A && At && bbox && pair_slot && nslot, DNMF_E_NULL, "dnmf_pack_footprints_lists: NULL buffer");
+    DNMF_REQUIRE(A && At && bbox && pair_slot && nslot && axis_masks, DNMF_E_NULL, "dnmf_pack_footprints_lists: NULL buffer");
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0, DNMF_E_SHAPE, "dnmf_pack_footprints_lists: X=%d Y=%d Z=%d K=%d", X, Y, Z,
                  K);
     DNMF_REQUIRE(K <= 64 * LISTS_MAXW, DNMF_E_UNSUPPORTED, "dnmf_pack_footprints_lists: K=%d > %d", K, 64 * LISTS_MAXW);
     const Volume vol = make_volume(X, Y, Z);
+    const HaloLayout hl = make_halo_layout(X, Y, Z);
     hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(At, 0, (size_t)K * hl.Pp * sizeof(float), st);
+    DNMF_REQUIRE(e == hipSuccess, (int)e, "dnmf_pack_footprints_lists: hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(lists_init_kernel, dim3((K * 6 + 255) / 256), dim3(256), 0, st, bbox, K);
     hipLaunchKernelGGL(lists_transpose_kernel, dim3((unsigned)((vol.P + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0,
-                       st, A, vol.P, K, vol, At, bbox);
+                       st, A, vol.P, K, vol, hl, At, bbox);
     hipLaunchKernelGGL(lists_pairs_kernel, dim3(1), dim3(256), 0, st, bbox, K, pair_slot, nslot);
+    hipLaunchKernelGGL(lists_axis_masks_kernel, dim3((unsigned)((axis_masks_entries(vol) + 255) / 256)), dim3(256), 0, st, bbox,
+                       K, vol, lists_words(K), static_cast<unsigned long long *>(axis_masks));
     return check_launch("dnmf_pack_footprints_lists");
 }
 
-size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int B) {
-    if (nslot <= 0 || B <= 0) return 0;
+// workspace = slot tables (B, nchunks, nslot) floats, then the tile lists (B, ntiles, NW) 64-bit words
+static size_t lists_slab_bytes(int nslot, int B) {
     long want = (dnmf::LISTS_ITEMS + B - 1) / B;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
-    return (size_t)B * (size_t)want * (size_t)nslot * sizeof(float);
+    return ((size_t)B * (size_t)want * (size_t)nslot * sizeof(float) + 255) / 256 * 256;
 }
 
-int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, int nslot, int K, int X, int Y, int Z,
-                             const float *beta, int T, const int *times, int B, const float *frames, long ldf,
-                             const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
+size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z, int B) {
+    using namespace dnmf;
+    if (nslot <= 0 || B <= 0 || K <= 0 || K > 64 * LISTS_MAXW || X <= 0 || Y <= 0 || Z <= 0) return 0;
+    int lgx, lgz, ntx, nty, ntz, ntiles;
+    lists_tile_shape(make_volume(X, Y, Z), lgx, lgz, ntx, nty, ntz, ntiles);
+    return lists_slab_bytes(nslot, B) + (size_t)B * ntiles * lists_words(K) * sizeof(unsigned long long);
+}
+
+int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, const void *axis_masks, int nslot, int K,
+                             int X, int Y, int Z, const float *beta, int T, const int *times, int B, const float *frames,
+                             long ldf, const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
                              unsigned long long *counters, dnmf_stream_t stream) {
     using namespace dnmf;
-    DNMF_REQUIRE(At && bbox && pair_slot && beta && frames && workspace && (!G == !r), DNMF_E_NULL,
+    DNMF_REQUIRE(At && bbox && pair_slot && axis_masks && beta && frames && workspace && (!G == !r), DNMF_E_NULL,
                  "dnmf_warp_gram_rhs_lists: NULL buffer");
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && nslot > K, DNMF_E_SHAPE,
                  "dnmf_warp_gram_rhs_lists: X=%d Y=%d Z=%d K=%d T=%d B=%d nslot=%d", X, Y, Z, K, T, B, nslot);
@@ -495,24 +694,27 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
                  LISTS_MAX_SLOTS);
     ListParams p;
     p.vol = make_volume(X, Y, Z);
+    p.hl = make_halo_layout(X, Y, Z);
     DNMF_REQUIRE(ldf >= p.vol.P, DNMF_E_SHAPE, "dnmf_warp_gram_rhs_lists: ldf=%ld < P=%ld", ldf, p.vol.P);
-    DNMF_REQUIRE(p.vol.P < (1L << 30), DNMF_E_UNSUPPORTED, "dnmf_warp_gram_rhs_lists: P=%ld does not fit 32-bit offsets",
-                 p.vol.P);
+    DNMF_REQUIRE(p.hl.Pp < (1L << 29) && p.hl.row4 < (1 << 23) && p.hl.Xp < (1 << 23), DNMF_E_UNSUPPORTED,
+                 "dnmf_warp_gram_rhs_lists: volume %dx%dx%d too large for 32-bit tap offsets", X, Y, Z);
     p.At = At, p.bbox = bbox, p.pair_slot = pair_slot, p.nslot = nslot, p.K = K;
+    p.axis_masks = static_cast<const unsigned long long *>(axis_masks);
     p.beta = beta, p.T = T, p.times = times, p.B = B;
     p.frames = frames, p.ldf = ldf, p.frame_ids = frame_ids;
     p.slab = static_cast<float *>(workspace);
+    p.tile_masks = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + lists_slab_bytes(nslot, B));
     p.counters = counters;
-    lists_tile_shape(p.vol, p.lgx, p.lgz, p.nty, p.ntz, p.ntiles);
+    lists_tile_shape(p.vol, p.lgx, p.lgz, p.ntx, p.nty, p.ntz, p.ntiles);
     lists_choose_chunks(p.ntiles, B, p.nchunks, p.chunk_len);
-    DNMF_REQUIRE(workspace_bytes >= (size_t)B * p.nchunks * nslot * sizeof(float), DNMF_E_WORKSPACE,
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B), DNMF_E_WORKSPACE,
                  "dnmf_warp_gram_rhs_lists: workspace %zu < %zu bytes", workspace_bytes,
-                 (size_t)B * p.nchunks * nslot * sizeof(float));
+                 dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B));
     hipStream_t st = (hipStream_t)stream;
     const long nitems = (long)p.nchunks * B;
     const unsigned nwg = (unsigned)((nitems + 3) / 4);
-    const int nw = K <= 64 ? 1 : (K <= 128 ? 2 : 4);
-    const size_t lds = (size_t)4 * (nslot + 64 * nw) * sizeof(float);
+    const int nw = lists_words(K);
+    const size_t lds = (size_t)4 * nslot * sizeof(float);
     if (Z > 1) {
         if (nw == 1) launch_lists_t<8, 1>(p, nwg, lds, st);
         else if (nw == 2) launch_lists_t<8, 2>(p, nwg, lds, st);
@@ -532,8 +734,8 @@ int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B) {
     using namespace dnmf;
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
     const Volume vol = make_volume(X, Y, Z);
-    int lgx, lgz, nty, ntz, ntiles, nchunks, chunk_len;
-    lists_tile_shape(vol, lgx, lgz, nty, ntz, ntiles);
+    int lgx, lgz, ntx, nty, ntz, ntiles, nchunks, chunk_len;
+    lists_tile_shape(vol, lgx, lgz, ntx, nty, ntz, ntiles);
     lists_choose_chunks(ntiles, B, nchunks, chunk_len);
     return nchunks;
 }

@@ -15,6 +15,14 @@ namespace dnmf {
 constexpr int K2_ROWS = 16;           // voxels per lane: consecutive x
 constexpr int K2_COLS = 256;          // positions of the (y,z) plane per block: 64 lanes x 4 waves
 constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
+#ifndef DNMF_K2_UNROLL
+#define DNMF_K2_UNROLL 2
+#endif
+#ifndef DNMF_K2_PIPE
+#define DNMF_K2_PIPE 0
+#endif
+constexpr int K2_UNROLL = DNMF_K2_UNROLL;  // rows requested together; two such sets alternate
+static_assert(K2_ROWS % (2 * K2_UNROLL) == 0, "the row loop alternates two sets of K2_UNROLL rows");
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -24,26 +32,35 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Work layout: a block owns 16 x-rows by 256 consecutive positions of the (y,z) plane (lane = position, so the frame
 // and the reconstruction image are read in 256-byte runs and the taps of neighbouring lanes share cache lines); a
-// thread walks down its 16 rows.  x, y, z follow from the block and lane indices by additions.
+// thread walks down its 16 rows with (y,z) fixed, so its warped coordinates are quadratics in x with per-thread
+// coefficients (poly_coeffs) and x, x^2 are the same for the whole block: they come from a table (scalar loads).
+//
+// S carries the zero halo of common.hpp around x and y: a tap outside the volume reads a zero instead of being
+// masked, for the value and for the gradient alike (grid_sample's backward skips out-of-bounds corners: it adds the
+// same zeros).  Per voxel that leaves: two FMAs per coordinate, the fp32 normalise / un-normalise round trip of the
+// reference, one clamp + floor + two weights per axis, one base offset, the taps, the blends.
 //
 // HASZ = false is the Z == 1 specialisation: two coordinates, four taps, and only the six basis terms without z
-// (the other 18 gradient sums are identically zero and are written as such).
-template <bool HASZ, int FAST>
+// (the other 18 gradient sums are identically zero and are written as such).  PLAIN = the fit step's call (frames
+// given, no upstream gradient, A_tC not wanted): the row loop then has no branches.
+template <bool HASZ, int FAST, bool F32OFF, bool PLAIN>
 __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
                                                               const int *__restrict__ s_ids,
                                                               const float *__restrict__ frames, long ldf,
                                                               const int *__restrict__ frame_ids,
-                                                              const float *__restrict__ gout, Volume vol,
+                                                              const float *__restrict__ gout, Volume vol, HaloLayout hl,
                                                               const float *__restrict__ beta, int T,
                                                               const int *__restrict__ times,
                                                               float *__restrict__ recon, float *__restrict__ partial,
-                                                              int nub) {
+                                                              const float2 *__restrict__ xtab, int nub) {
     constexpr int ND = HASZ ? 3 : 2;                 // warped coordinates that exist
     constexpr int NA = HASZ ? 10 : 6;                // basis terms that are not identically zero
     constexpr int BASIS_ID[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};  // z-free terms first
     const int b = blockIdx.y;
     const char *__restrict__ s = reinterpret_cast<const char *>(S + (long)(s_ids ? s_ids[b] : b) * lds);
     const float *__restrict__ y = frames ? frames + (long)(frame_ids ? frame_ids[b] : b) * ldf : nullptr;
+    const float *__restrict__ go = !PLAIN && gout ? gout + (long)b * vol.P : nullptr;
+    float *__restrict__ rc = !PLAIN && recon ? recon + (long)b * vol.P : nullptr;
     float bt[30];
     load_beta(beta, T, times[b], bt);
 
@@ -63,66 +80,135 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     const float yf = (float)yy, zf = (float)z;
 
     if (u < YZ) {
-        const int nrow = min(K2_ROWS, vol.X - bx * K2_ROWS);
-#pragma unroll 2
-        for (int i = 0; i < nrow; ++i) {
-            const int x = bx * K2_ROWS + i;
-            const long p = (long)x * YZ + u;
-            const Sample sm = make_sample_t<HASZ, FAST>(bt, vol, x, yy, z);
-            // Branch-free gather: corner indices clamped into the volume, per-axis weights (w) and validity flags (v)
-            // zeroed for corners outside it.  A corner's value weight is wx*wy*wz and its x-derivative weight
-            // +-vx*wy*wz (ATen's grid_sampler backward skips out-of-bounds corners), so everything factorises per
-            // axis.
-            const float wx[2] = {in_range(sm.x0, vol.X) ? sm.wx0 : 0.0f, in_range(sm.x0 + 1, vol.X) ? sm.wx1 : 0.0f};
-            const float wy[2] = {in_range(sm.y0, vol.Y) ? sm.wy0 : 0.0f, in_range(sm.y0 + 1, vol.Y) ? sm.wy1 : 0.0f};
-            const float vx[2] = {in_range(sm.x0, vol.X) ? 1.0f : 0.0f, in_range(sm.x0 + 1, vol.X) ? 1.0f : 0.0f};
-            const float vy[2] = {in_range(sm.y0, vol.Y) ? 1.0f : 0.0f, in_range(sm.y0 + 1, vol.Y) ? 1.0f : 0.0f};
-            const unsigned xo[2] = {(unsigned)(clamp_index(sm.x0, vol.X) * YZ), (unsigned)(clamp_index(sm.x0 + 1, vol.X) * YZ)};
-            const unsigned yo[2] = {(unsigned)(clamp_index(sm.y0, vol.Y) * vol.Z),
-                                    (unsigned)(clamp_index(sm.y0 + 1, vol.Y) * vol.Z)};
+        float c[ND][3];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) poly_coeffs<HASZ>(bt, d, yf, zf, c[d]);
+        const int x_first = bx * K2_ROWS;
+        const int nrow = min(K2_ROWS, vol.X - x_first);
+
+        // A row is handled in two steps so that the loop below can keep the taps of the next rows in flight while
+        // it blends the current ones: request() = coordinates, weights, tap offsets, loads; consume() = the blends,
+        // the residual and the moment sums.
+        struct Req {
+            float2 xv;                    // (x, x*x): block-uniform
+            float sv[HASZ ? 2 : 1][2][2];  // [dz][dy][dx]
+            float wx[2], wy[2], wzm[2], vz[2];
+            float other;                  // frame value, or the caller's upstream gradient
+            long prow;
+        };
+        unsigned u4 = (unsigned)u * 4u;
+        auto request = [&](int x, Req &q) {
+            q.xv = xtab[x];                   // a scalar load
+            q.prow = (long)x * YZ;            // block-uniform: (scalar base + 32-bit lane offset) accesses
+            float fx, fy;
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[0], q.xv.x, q.xv.y), vol, 0), vol.hx1), hl.xhi, fx,
+                           q.wx[0], q.wx[1]);
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[1], q.xv.x, q.xv.y), vol, 1), vol.hy1), hl.yhi, fy,
+                           q.wy[0], q.wy[1]);
+            const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);   // base corner, slice 0
+            int iz = 0;
+            if (HASZ) {
+                float wz[2];
+                axis_weights(unnormalise(normalise_axis<FAST>(poly_a(c[ND - 1], q.xv.x, q.xv.y), vol, 2), vol.hz1), iz, wz[0],
+                             wz[1]);
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz) {
+                    const bool zin = in_range(iz + dz, vol.Z);
+                    q.wzm[dz] = zin ? wz[dz] : 0.0f;
+                    q.vz[dz] = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
+                const unsigned zo = HASZ ? (unsigned)clamp_index(iz + dz, vol.Z) * 4u : 0u;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    unsigned o = o0 + zo + (dx ? (unsigned)hl.row4 : 0u);   // (scalar base + 32-bit offset) loads
+                    asm("" : "+v"(o));
+                    const char *t = s + o;
+                    q.sv[dz][0][dx] = *reinterpret_cast<const float *>(t);
+                    q.sv[dz][1][dx] = *reinterpret_cast<const float *>(t + (HASZ ? hl.col4 : 4));
+                }
+            }
+            asm("" : "+v"(u4));
+            q.other = *reinterpret_cast<const float *>(reinterpret_cast<const char *>((!PLAIN && go ? go : y) + q.prow) + u4);
+        };
+        auto consume = [&](const Req &q) {
             float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-                const unsigned zo = HASZ ? (unsigned)clamp_index(sm.z0 + dz, vol.Z) : 0u;
-                float sv[2][2];  // [dy][dx]
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        unsigned o = (xo[dx] + yo[dy] + zo) * 4u;  // byte offset: (scalar base + 32-bit offset) loads
-                        asm("" : "+v"(o));
-                        sv[dy][dx] = *reinterpret_cast<const float *>(s + o);
-                    }
-                const float a0 = fmaf(wx[1], sv[0][1], wx[0] * sv[0][0]);  // x-interpolated rows y0, y1
-                const float a1 = fmaf(wx[1], sv[1][1], wx[0] * sv[1][0]);
-                const float d0 = fmaf(vx[1], sv[0][1], -(vx[0] * sv[0][0]));  // x-differences of the rows
-                const float d1 = fmaf(vx[1], sv[1][1], -(vx[0] * sv[1][0]));
-                const float r2 = fmaf(wy[1], a1, wy[0] * a0);       // value of this z-slice
-                const float gx2 = fmaf(wy[1], d1, wy[0] * d0);
-                const float gy2 = fmaf(vy[1], a1, -(vy[0] * a0));
+                const float a0 = fmaf(q.wx[1], q.sv[dz][0][1], q.wx[0] * q.sv[dz][0][0]);  // x-interpolated rows y0, y1
+                const float a1 = fmaf(q.wx[1], q.sv[dz][1][1], q.wx[0] * q.sv[dz][1][0]);
+                const float d0 = q.sv[dz][0][1] - q.sv[dz][0][0];                          // x-differences of the rows
+                const float d1 = q.sv[dz][1][1] - q.sv[dz][1][0];
+                const float r2 = fmaf(q.wy[1], a1, q.wy[0] * a0);                          // value of this z-slice
+                const float gx2 = fmaf(q.wy[1], d1, q.wy[0] * d0);
+                const float gy2 = a1 - a0;
                 if (HASZ) {
-                    const bool zin = in_range(sm.z0 + dz, vol.Z);
-                    const float wz = zin ? (dz ? sm.wz1 : sm.wz0) : 0.0f;
-                    const float vz = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
-                    rec = fmaf(wz, r2, rec);
-                    g[0] = fmaf(wz, gx2, g[0]);
-                    g[1] = fmaf(wz, gy2, g[1]);
-                    g[2] = fmaf(vz, r2, g[2]);
+                    rec = fmaf(q.wzm[dz], r2, rec);
+                    g[0] = fmaf(q.wzm[dz], gx2, g[0]);
+                    g[1] = fmaf(q.wzm[dz], gy2, g[1]);
+                    g[2] = fmaf(q.vz[dz], r2, g[2]);
                 } else {
                     rec = r2, g[0] = gx2, g[1] = gy2;
                 }
             }
-            if (recon) recon[(long)b * vol.P + p] = rec;
+            if (!PLAIN && rc) *reinterpret_cast<float *>(reinterpret_cast<char *>(rc + q.prow) + u4) = rec;
             // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
-            const float resid = gout ? gout[(long)b * vol.P + p] : rec - y[p];
+            const float resid = !PLAIN && go ? q.other : rec - q.other;
             sq = fmaf(resid, resid, sq);
-            const float xf = (float)x, xx = xf * xf;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const float gd = resid * g[d];
                 mom[0][d] += gd;
-                mom[1][d] = fmaf(xf, gd, mom[1][d]);
-                mom[2][d] = fmaf(xx, gd, mom[2][d]);
+                mom[1][d] = fmaf(q.xv.x, gd, mom[1][d]);
+                mom[2][d] = fmaf(q.xv.y, gd, mom[2][d]);
+            }
+        };
+        if (nrow == K2_ROWS) {
+#if DNMF_K2_PIPE
+            // two sets of K2_UNROLL rows, ping-pong: one set's taps are in flight while the other is blended
+            Req qa[K2_UNROLL], qb[K2_UNROLL];
+#pragma unroll
+            for (int j = 0; j < K2_UNROLL; ++j) request(x_first + j, qa[j]);
+#pragma unroll 1
+            for (int i = 0; i + 2 * K2_UNROLL < K2_ROWS; i += 2 * K2_UNROLL) {
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + K2_UNROLL + j, qb[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) consume(qa[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + 2 * K2_UNROLL + j, qa[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) consume(qb[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < K2_UNROLL; ++j) request(x_first + K2_ROWS - K2_UNROLL + j, qb[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < K2_UNROLL; ++j) consume(qa[j]);
+#pragma unroll
+            for (int j = 0; j < K2_UNROLL; ++j) consume(qb[j]);
+#else
+            // K2_UNROLL rows at a time: their taps are requested together, then blended
+#pragma unroll 1
+            for (int i = 0; i < K2_ROWS; i += K2_UNROLL) {
+                Req q[K2_UNROLL];
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + j, q[j]);
+#pragma unroll
+                for (int j = 0; j < K2_UNROLL; ++j) consume(q[j]);
+            }
+#endif
+        } else {
+            for (int i = 0; i < nrow; ++i) {
+                Req q;
+                request(x_first + i, q);
+                consume(q);
             }
         }
     }
@@ -158,6 +244,15 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     if (threadIdx.x < K2_NACC) {
         const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         partial[((long)b * gridDim.x + blockIdx.x) * K2_NACC + threadIdx.x] = v;
+    }
+}
+
+// (x, x*x) as floats for every x of the volume: the table the main kernel reads with scalar loads
+__global__ void k2_xtab_kernel(float2 *__restrict__ xtab, int X) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < X) {
+        const float xf = (float)x;
+        xtab[x] = make_float2(xf, __fmul_rn(xf, xf));
     }
 }
 
@@ -232,9 +327,22 @@ static long k2_blocks(int X, int Y, int Z, int *nub_out) {
     return nub * ((X + dnmf::K2_ROWS - 1) / dnmf::K2_ROWS);
 }
 
+static size_t k2_xtab_bytes(int X) { return ((size_t)X * sizeof(float2) + 255) / 256 * 256; }
+
 size_t dnmf_warp_recon_grad_workspace(int X, int Y, int Z, int B) {
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
-    return (size_t)B * k2_blocks(X, Y, Z, nullptr) * dnmf::K2_NACC * sizeof(float) + (size_t)B * sizeof(float);
+    return k2_xtab_bytes(X) + (size_t)B * k2_blocks(X, Y, Z, nullptr) * dnmf::K2_NACC * sizeof(float) +
+           (size_t)B * sizeof(float);
+}
+
+long dnmf_halo_voxels(int X, int Y, int Z) {
+    if (X <= 0 || Y <= 0 || Z <= 0) return 0;
+    return dnmf::make_halo_layout(X, Y, Z).Pp;
+}
+
+int dnmf_halo_row(int Y, int Z) {
+    if (Y <= 0 || Z <= 0) return 0;
+    return dnmf::make_halo_layout(1, Y, Z).rowf;
 }
 
 int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
@@ -247,29 +355,39 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && T > 0 && B > 0 && B <= 65535, DNMF_E_SHAPE,
                  "dnmf_warp_recon_grad: X=%d Y=%d Z=%d T=%d B=%d", X, Y, Z, T, B);
     const Volume vol = make_volume(X, Y, Z);
-    DNMF_REQUIRE(lds >= vol.P && (!frames || ldf >= vol.P), DNMF_E_SHAPE, "dnmf_warp_recon_grad: lds=%ld ldf=%ld < P=%ld", lds,
-                 ldf, vol.P);
+    const HaloLayout hl = make_halo_layout(X, Y, Z);
+    DNMF_REQUIRE(lds >= hl.Pp && (!frames || ldf >= vol.P), DNMF_E_SHAPE,
+                 "dnmf_warp_recon_grad: lds=%ld < %ld (halo layout) or ldf=%ld < P=%ld", lds, hl.Pp, ldf, vol.P);
     DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(X, Y, Z, B), DNMF_E_WORKSPACE,
                  "dnmf_warp_recon_grad: workspace %zu < %zu bytes", workspace_bytes,
                  dnmf_warp_recon_grad_workspace(X, Y, Z, B));
-    DNMF_REQUIRE(vol.P < (1L << 30), DNMF_E_UNSUPPORTED, "dnmf_warp_recon_grad: P=%ld does not fit 32-bit byte offsets",
-                 vol.P);
+    // 32-bit byte offsets into an image; 24-bit multiplies for the tap offsets
+    DNMF_REQUIRE(hl.Pp < (1L << 29) && hl.row4 < (1 << 23) && hl.Xp < (1 << 23), DNMF_E_UNSUPPORTED,
+                 "dnmf_warp_recon_grad: volume %dx%dx%d too large for 32-bit tap offsets", X, Y, Z);
     int nub = 0;
     const long nblk_l = k2_blocks(X, Y, Z, &nub);
     DNMF_REQUIRE(nblk_l < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_warp_recon_grad: %ld blocks per frame", nblk_l);
     const int nblk = (int)nblk_l;
-    float *partial = static_cast<float *>(workspace);
+    float2 *xtab = static_cast<float2 *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + k2_xtab_bytes(X));
     float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k2_xtab_kernel, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, st, xtab, X);
     const dim3 grid((unsigned)nblk, (unsigned)B);
-#define DNMF_K2_LAUNCH(HZ, FD)                                                                                            \
-    hipLaunchKernelGGL((warp_recon_grad_kernel<HZ, FD>), grid, dim3(256), 0, st, S, lds, s_ids, frames, ldf, frame_ids, \
-                       gout, vol, beta, T, times, recon, partial, nub)
+#define DNMF_K2_LAUNCH(HZ, FD, FO, PL)                                                                                     \
+    hipLaunchKernelGGL((warp_recon_grad_kernel<HZ, FD, FO, PL>), grid, dim3(256), 0, st, S, lds, s_ids, frames, ldf,      \
+                       frame_ids, gout, vol, hl, beta, T, times, recon, partial, xtab, nub)
+#define DNMF_K2_VARIANTS(HZ, PL)                                    \
+    if (vol.fastdiv && hl.f32off) DNMF_K2_LAUNCH(HZ, 1, true, PL);  \
+    else if (vol.fastdiv) DNMF_K2_LAUNCH(HZ, 1, false, PL);         \
+    else DNMF_K2_LAUNCH(HZ, 0, false, PL)
+    const bool plain = frames && !gout && !recon;
     if (Z > 1) {
-        if (vol.fastdiv) DNMF_K2_LAUNCH(true, 1); else DNMF_K2_LAUNCH(true, 0);
+        if (plain) { DNMF_K2_VARIANTS(true, true); } else { DNMF_K2_VARIANTS(true, false); }
     } else {
-        if (vol.fastdiv) DNMF_K2_LAUNCH(false, 1); else DNMF_K2_LAUNCH(false, 0);
+        if (plain) { DNMF_K2_VARIANTS(false, true); } else { DNMF_K2_VARIANTS(false, false); }
     }
+#undef DNMF_K2_VARIANTS
 #undef DNMF_K2_LAUNCH
     if (norm_frames <= 0) norm_frames = B;
     const float grad_scale = gout ? 1.0f : 2.0f / ((float)norm_frames * (float)vol.P);

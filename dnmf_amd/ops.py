@@ -53,6 +53,23 @@ def padded_k(K: int) -> int:
     return _lib.load().dnmf_padded_k(int(K))
 
 
+HALO = 2   # DNMF_HALO of include/dnmf_hip.h
+
+
+def halo_voxels(sz) -> int:
+    """Floats of one halo-layout image (reconstruction image S, neuron-major footprint At) of the volume ``sz``."""
+    X, Y, Z = (int(s) for s in sz)
+    return _lib.load().dnmf_halo_voxels(X, Y, Z)
+
+
+def halo_interior(img: torch.Tensor, sz) -> torch.Tensor:
+    """(..., >= halo_voxels) rows in the halo layout -> (..., X, Y, Z) view of the voxels without the border."""
+    X, Y, Z = (int(s) for s in sz)
+    row = _lib.load().dnmf_halo_row(Y, Z)
+    v = img[..., :(X + 2 * HALO) * row].unflatten(-1, (X + 2 * HALO, row))   # views all the way
+    return v[..., HALO:HALO + X, HALO * Z:(HALO + Y) * Z].unflatten(-1, (Y, Z))
+
+
 def pack_footprints(A: torch.Tensor) -> torch.Tensor:
     """A (..., K) -> packed (P, Kp) zero-padded copy the Gram / recon kernels read."""
     K = A.shape[-1]
@@ -77,34 +94,39 @@ def warp_gather(A: torch.Tensor, beta: torch.Tensor, times, want_A_t=True, want_
     return A_t, grid
 
 
-def recon_image(Apk: torch.Tensor, K: int, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
-    """S[b,p] = sum_k C[k,times[b]] A[p,k].  Apk (P,Kp), C (K,T) -> (B,P)."""
+def recon_image(Apk: torch.Tensor, K: int, sz, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
+    """S[b] = sum_k C[k,times[b]] A[:,k] in the halo layout.  Apk (P,Kp), C (K,T) -> (B, halo_voxels(sz))."""
+    X, Y, Z = (int(s) for s in sz)
     _f32(Apk, "Apk"), _f32(C, "C")
     P, Kp = Apk.shape
+    if P != X * Y * Z:
+        raise ValueError(f"recon_image: Apk has {P} rows, the volume {X}x{Y}x{Z} has {X * Y * Z} voxels")
     tt = _i32(times, Apk.device)
     B = tt.numel()
-    lds = (P + 3) // 4 * 4
+    lds = halo_voxels(sz)
     if out is None:
         out = torch.empty((B, lds), dtype=torch.float32, device=Apk.device)
-    if out.shape[0] < B or out.stride(0) % 4 or out.stride(0) < P or out.stride(1) != 1:
-        raise ValueError("recon_image: out must be (>=B, ld) with ld >= P and ld % 4 == 0")
-    _lib.check(_lib.load().dnmf_recon_image(Apk.data_ptr(), P, K, Kp, C.data_ptr(), C.stride(0), tt.data_ptr(), B,
-                                            out.data_ptr(), out.stride(0), _stream()), "dnmf_recon_image")
+    if out.shape[0] < B or out.stride(0) < lds or out.stride(1) != 1:
+        raise ValueError("recon_image: out must be (>=B, ld) with ld >= halo_voxels(sz)")
+    for s in range(0, B, 32768):   # frames ride on gridDim.y
+        n = min(32768, B - s)
+        _lib.check(_lib.load().dnmf_recon_image(Apk.data_ptr(), X, Y, Z, K, Kp, C.data_ptr(), C.stride(0),
+                                                tt[s:].data_ptr(), n, out[s:].data_ptr(), out.stride(0), _stream()),
+                   "dnmf_recon_image")
     return out
 
 
 def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
     """S as ``recon_image`` from the K3n layout (``pack_footprints_lists``): compact footprints, static tile lists."""
     X, Y, Z = (int(s) for s in sz)
-    P = X * Y * Z
     _f32(C, "C")
     tt = _i32(times, C.device)
     B = tt.numel()
-    lds = (P + 3) // 4 * 4
+    lds = halo_voxels(sz)
     if out is None:
         out = torch.empty((B, lds), dtype=torch.float32, device=C.device)
-    if out.shape[0] < B or out.stride(0) < P or out.stride(1) != 1:
-        raise ValueError("recon_image_lists: out must be (>=B, ld) with ld >= P")
+    if out.shape[0] < B or out.stride(0) < lds or out.stride(1) != 1:
+        raise ValueError("recon_image_lists: out must be (>=B, ld) with ld >= halo_voxels(sz)")
     with _timed("recon_image_lists"):
         rc = _lib.load().dnmf_recon_image_lists(layout["At"].data_ptr(), layout["bbox"].data_ptr(), K, X, Y, Z,
                                                 C.data_ptr(), C.stride(0), tt.data_ptr(), B, out.data_ptr(),
@@ -115,7 +137,7 @@ def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Ten
 
 def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gout=None, want_recon=False,
                     want_loss=True, want_reg=True, workspace=None, norm_frames=0):
-    """K2.  S (>=B, lds) recon images, frames (>=B, ldf) or None with gout (B,P).
+    """K2.  S (>=B, lds) recon images in the halo layout, frames (>=B, ldf) or None with gout (B,P).
     Returns dict(recon, loss, frame_loss, reg); ``grad`` (10,3,T) is incremented in place."""
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
@@ -282,12 +304,14 @@ def pack_footprints_lists(A, sz):
     K = A.shape[-1]
     A2 = _f32(A.reshape(-1, K), "A")
     dev = A.device
-    At = torch.empty((K, A2.shape[0]), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    At = torch.empty((K, halo_voxels(sz)), dtype=torch.float32, device=dev)   # halo layout, border zeroed by the call
     bbox = torch.empty((K, 6), dtype=torch.int32, device=dev)
     pair_slot = torch.empty((K, K), dtype=torch.int32, device=dev)
     nslot = torch.zeros((1,), dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().dnmf_pack_footprints_lists(A2.data_ptr(), X, Y, Z, K, At.data_ptr(), bbox.data_ptr(),
-                                                      pair_slot.data_ptr(), nslot.data_ptr(), _stream()),
+    axis_masks = torch.empty((lib.dnmf_lists_axis_masks_bytes(X, Y, Z, K) // 8,), dtype=torch.int64, device=dev)
+    _lib.check(lib.dnmf_pack_footprints_lists(A2.data_ptr(), X, Y, Z, K, At.data_ptr(), bbox.data_ptr(),
+                                              pair_slot.data_ptr(), nslot.data_ptr(), axis_masks.data_ptr(), _stream()),
                "dnmf_pack_footprints_lists")
     bb = bbox.cpu().long()
     ext = (bb[:, 1::2] - bb[:, 0::2] + 1).clamp_min(0)
@@ -299,7 +323,7 @@ def pack_footprints_lists(A, sz):
     nbr = None
     if NN is not None:
         nbr = torch.argsort((~pattern).to(torch.uint8), dim=1, stable=True)[:, :NN].to(torch.int32).contiguous()
-    return {"At": At, "bbox": bbox, "pair_slot": pair_slot, "nslot": ns, "nbr": nbr,
+    return {"At": At, "bbox": bbox, "pair_slot": pair_slot, "nslot": ns, "nbr": nbr, "axis_masks": axis_masks,
             "boxfrac": float(ext.prod(1).sum()) / (X * Y * Z)}
 
 
@@ -322,7 +346,7 @@ def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, work
     if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
         raise ValueError("warp_gram_rhs_lists: frames must be float32 CUDA with unit inner stride")
     nslot = layout["nslot"]
-    need = lib.dnmf_warp_gram_rhs_lists_workspace(nslot, B)
+    need = lib.dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     G = torch.empty((B, K, K), dtype=torch.float32, device=dev) if finish else None
@@ -334,7 +358,8 @@ def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, work
         counters = LISTS_COUNTERS
     with _timed("warp_gram_rhs_lists"):
         rc = lib.dnmf_warp_gram_rhs_lists(
-            layout["At"].data_ptr(), layout["bbox"].data_ptr(), layout["pair_slot"].data_ptr(), nslot, K, X, Y, Z,
+            layout["At"].data_ptr(), layout["bbox"].data_ptr(), layout["pair_slot"].data_ptr(),
+            layout["axis_masks"].data_ptr(), nslot, K, X, Y, Z,
             beta.data_ptr(), beta.shape[2], _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), _ptr(G),
             _ptr(r), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _ptr(counters), _stream())
     _lib.check(rc, "dnmf_warp_gram_rhs_lists")
@@ -398,8 +423,10 @@ class Communicator:
             self._handle = None
 
 
-def image_iwarp(frames, frame_ids, sz, beta, times):
-    """K7.  Registered frames (B,P): nearest-neighbour inverse warp under beta[:, :, times]."""
+def image_iwarp(frames, frame_ids, sz, beta, times, out=None, exhaustive=False, count=None):
+    """K7.  Registered frames (B,P): nearest-neighbour inverse warp under beta[:, :, times].  ``exhaustive``: search
+    all P candidates for every lattice point (the checker of the window search); ``count``: int64[1] CUDA tensor
+    incremented by the lattice points that needed the exhaustive search."""
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
     _f32(beta, "beta")
@@ -409,10 +436,20 @@ def image_iwarp(frames, frame_ids, sz, beta, times):
     tt = _i32(times, dev)
     fid = _i32(frame_ids, dev) if frame_ids is not None else None
     B = tt.numel()
-    out = torch.empty((B, P), dtype=torch.float32, device=dev)
-    _lib.check(_lib.load().dnmf_image_iwarp(frames.data_ptr(), frames.stride(0), _ptr(fid), X, Y, Z, beta.data_ptr(),
-                                            beta.shape[2], tt.data_ptr(), B, out.data_ptr(), out.stride(0), _stream()),
-               "dnmf_image_iwarp")
+    if out is None:
+        out = torch.empty((B, P), dtype=torch.float32, device=dev)
+    if out.shape[0] < B or out.stride(0) < P or out.stride(1) != 1:
+        raise ValueError("image_iwarp: out must be (>=B, ld) with ld >= P")
+    lib = _lib.load()
+    step = 16384   # frames per launch (gridDim.y); one flag byte per lattice point of the launch
+    ws = torch.empty((lib.dnmf_image_iwarp_workspace(X, Y, Z, min(B, step)),), dtype=torch.uint8, device=dev)
+    for s in range(0, B, step):
+        n = min(step, B - s)
+        src = frames if fid is not None else frames[s:]   # without ids, frame b of a launch is its row b
+        _lib.check(lib.dnmf_image_iwarp(src.data_ptr(), frames.stride(0), 0 if fid is None else fid[s:].data_ptr(), X, Y, Z,
+                                        beta.data_ptr(), beta.shape[2], tt[s:].data_ptr(), n, out[s:].data_ptr(),
+                                        out.stride(0), ws.data_ptr(), ws.numel(), int(bool(exhaustive)), _ptr(count),
+                                        _stream()), "dnmf_image_iwarp")
     return out
 
 

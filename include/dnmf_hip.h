@@ -18,7 +18,15 @@
  *     p = (x*Y + y)*Z + z, P = X*Y*Z; footprints A are (P,K) (= torch (X,Y,Z,K) contiguous,
  *     Demix/dNMF.py:39-40); beta is (10,3,T) contiguous (Demix/dNMF.py:24-27); traces C are (K,T)
  *     with row stride ldc (Demix/dNMF.py:130); a frame is P floats;
- *   - Z == 1 means "z pinned to slice 0" (the reference divides 0/0 there; see oracle/dnmf_oracle.py).
+ *   - Z == 1 means "z pinned to slice 0" (the reference divides 0/0 there; see oracle/dnmf_oracle.py);
+ *   - HALO LAYOUT: the two single-channel images the hot kernels gather from -- the reconstruction images S
+ *     (read by K2) and the neuron-major footprints At (read by K3n) -- carry a zero border of DNMF_HALO voxels
+ *     around x and y: voxel (x,y,z) lives at (x + DNMF_HALO)*row + (y + DNMF_HALO)*Z + z with
+ *     row = dnmf_halo_row(Y,Z) = (Y + 2*DNMF_HALO)*Z rounded up to a multiple of 32 floats (rows start on 128-byte
+ *     lines), and an image has dnmf_halo_voxels(X,Y,Z) = (X + 2*DNMF_HALO)*row floats.  A trilinear tap outside the
+ *     volume then reads a zero, which is what grid_sample's zero padding (Demix/dNMF.py:57) contributes, without
+ *     per-corner bounds tests.  The kernels that WRITE such images (dnmf_recon_image*, dnmf_pack_footprints_lists)
+ *     write the border (and the alignment excess of every row) too.
  */
 #ifndef DNMF_HIP_H
 #define DNMF_HIP_H
@@ -29,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DNMF_ABI_VERSION 1
+#define DNMF_ABI_VERSION 2
 
 #define DNMF_OK 0
 #define DNMF_E_NULL (-1)      /* required pointer is NULL */
@@ -38,6 +46,11 @@ extern "C" {
 #define DNMF_E_WORKSPACE (-4) /* workspace too small */
 
 typedef void *dnmf_stream_t;
+
+#define DNMF_HALO 2
+/* Floats of one row / of one whole halo-layout image of an X x Y x Z volume (0 on bad sizes). */
+int dnmf_halo_row(int Y, int Z);
+long dnmf_halo_voxels(int X, int Y, int Z);
 
 /* ABI version of the loaded library (DNMF_ABI_VERSION). */
 int dnmf_version(void);
@@ -63,15 +76,16 @@ int dnmf_warp_gather(const float *A, int X, int Y, int Z, int K, const float *be
 /* ---- reconstruction image ------------------------------------------------------------------------
  * S[b,p] = sum_k C[k,times[b]] * A[p,k]  (fp32 MFMA).  Because the trilinear gather is linear in the
  * footprints, A_tC of Demix/dNMF.py:58 equals the gather of this single image; K2 consumes it.
- *   Apk (P,Kp) packed footprints; C (K,T) row stride ldc; S (B,P) row stride lds (floats) */
-int dnmf_recon_image(const float *Apk, long P, int K, int Kp, const float *C, long ldc, const int *times,
+ *   Apk (P,Kp) packed footprints, P = X*Y*Z; C (K,T) row stride ldc;
+ *   S (B, halo layout) row stride lds >= dnmf_halo_voxels(X,Y,Z) floats, border written as zeros */
+int dnmf_recon_image(const float *Apk, int X, int Y, int Z, int K, int Kp, const float *C, long ldc, const int *times,
                      int B, float *S, long lds, dnmf_stream_t stream);
 
 /* ---- K2: fused warp + reconstruction + loss + d loss / d beta --------------------------------------
  * One mini-batch of update_motion (Demix/dNMF.py:186-190): forward (dNMF.py:54-58), F.mse_loss
  * (dNMF.py:188, mean over B*P) and its autograd gradient w.r.t. beta[:,:,times]; also reg of
  * dNMF.py:60-61 (gradient-free in the reference).
- *   S       recon images, frame b at S + s_ids[b]*lds (s_ids NULL -> b)
+ *   S       recon images in the halo layout (zero border), frame b at S + s_ids[b]*lds (s_ids NULL -> b)
  *   frames  video frames, frame b at frames + frame_ids[b]*ldf (frame_ids NULL -> b)
  *   gout    NULL, or (B,P) upstream gradient d L / d A_tC of an arbitrary loss: then grad receives
  *           its chain through the warp unscaled, `frames` may be NULL and loss / frame_loss are
@@ -149,25 +163,28 @@ int dnmf_warp_gram_rhs_sparse_lt(const float *Aps, int Ks, int K, const int *ord
  * A_t^T A_t is a sum of products with an exact zero.  This kernel evaluates, per tile of 256 voxels, only the neurons
  * whose box the tile's taps can reach, on the vector ALU; sums are those of dnmf_warp_gram_rhs up to the order of
  * fp32 additions and are deterministic.  K <= 256.
- * dnmf_pack_footprints_lists: At (K,P) <- A (P,K) transposed; bbox (K,6) int32 = xlo,xhi,ylo,yhi,zlo,zhi of the
- *   non-zeros of each footprint; pair_slot (K,K) int32 and *nslot (one int32, DEVICE) = the static pattern of G:
- *   slots [0,K) hold r, the following ones the pairs (k,l) whose boxes can meet under one tap cell, the last one
- *   (nslot-1) collects everything else.  The caller reads *nslot back once to size the workspace.
+ * dnmf_pack_footprints_lists: At (K, halo layout) <- A (P,K) transposed, border zeroed; bbox (K,6) int32 =
+ *   xlo,xhi,ylo,yhi,zlo,zhi of the non-zeros of each footprint; pair_slot (K,K) int32 and *nslot (one int32, DEVICE) =
+ *   the static pattern of G: slots [0,K) hold r, the following ones the pairs (k,l) whose boxes can meet under one tap
+ *   cell, the last one (nslot-1) collects everything else; axis_masks (dnmf_lists_axis_masks_bytes(X,Y,Z,K) bytes) =
+ *   per axis and coordinate the set of neurons whose box starts at or before / ends at or after it, from which the
+ *   neuron list of a tile is three pairs of lookups.  The caller reads *nslot back once to size the workspace.
  * dnmf_warp_gram_rhs_lists: other arguments and results as dnmf_warp_gram_rhs (G dense (B,K,K), r (B,K); both NULL:
- *   the slot tables are left in the workspace for dnmf_mu_temporal_slots);
+ *   the slot tables are left at the start of the workspace for dnmf_mu_temporal_slots);
  *   nslot <= 3800 (DNMF_E_UNSUPPORTED beyond: the footprints overlap too much, use K3 / K3s);
- *   workspace: dnmf_warp_gram_rhs_lists_workspace(nslot,B) bytes;
+ *   workspace: dnmf_warp_gram_rhs_lists_workspace(nslot,K,X,Y,Z,B) bytes (slot tables, then the tile lists);
  *   counters: NULL, or 2 x uint64 INCREMENTED by the (tile, neuron) evaluations and the (tile, pair) sums done. */
+size_t dnmf_lists_axis_masks_bytes(int X, int Y, int Z, int K);
 int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float *At, int *bbox, int *pair_slot,
-                               int *nslot, dnmf_stream_t stream);
-size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int B);
+                               int *nslot, void *axis_masks, dnmf_stream_t stream);
+size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z, int B);
 int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B); /* chunk tables per frame the launch will write */
-int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, int nslot, int K, int X, int Y,
-                             int Z, const float *beta, int T, const int *times, int B, const float *frames, long ldf,
-                             const int *frame_ids, float *G, float *r, void *workspace, size_t workspace_bytes,
-                             unsigned long long *counters, dnmf_stream_t stream);
+int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, const void *axis_masks, int nslot,
+                             int K, int X, int Y, int Z, const float *beta, int T, const int *times, int B,
+                             const float *frames, long ldf, const int *frame_ids, float *G, float *r, void *workspace,
+                             size_t workspace_bytes, unsigned long long *counters, dnmf_stream_t stream);
 
-/* Reconstruction image from the K3n layout: S as dnmf_recon_image, summing per tile of 4 x 64 voxels only the neurons
+/* Reconstruction image from the K3n layout: S (halo layout) as dnmf_recon_image, summing per tile of 4 x 64 voxels only the neurons
  * whose box meets the tile (static lists); bound by writing S.  K <= 256. */
 int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
                            const int *times, int B, float *S, long lds, dnmf_stream_t stream);
@@ -234,9 +251,17 @@ int dnmf_comm_destroy(dnmf_comm_t comm);
 /* ---- K7: registered video ---------------------------------------------------------------------------
  * ExponentialFP.image_iwarp over the frames of spatial_pushforward (Demix/dNMF.py:81-83, 89-91, 95-103): every
  * lattice point takes the value of the voxel whose warped position ((n+1)/2 * sz, the reference's scaling
- * there) is nearest.  Exhaustive search, P <= 2^20.  out (B,P) row stride ldo. */
+ * there) is nearest (float64 distances on the fp32 positions, ties to the lowest voxel index).  The search runs in
+ * a window around the back-mapped lattice point whose radius follows from a lower bound of the warp's stretch, so
+ * it returns what an exhaustive search returns; lattice points whose window would be too large (a folding or
+ * violent warp, points far outside the warped image) are searched exhaustively.
+ *   out (B,P) row stride ldo;  workspace: dnmf_image_iwarp_workspace(X,Y,Z,B) bytes (one flag per lattice point);
+ *   exhaustive != 0: every lattice point by the exhaustive search (the checker of the window search);
+ *   fallback_count: NULL, or one uint64 INCREMENTED by the lattice points that took the exhaustive search. */
+size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B);
 int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta,
-                     int T, const int *times, int B, float *out, long ldo, dnmf_stream_t stream);
+                     int T, const int *times, int B, float *out, long ldo, void *workspace, size_t workspace_bytes,
+                     int exhaustive, unsigned long long *fallback_count, dnmf_stream_t stream);
 
 /* ---- Adam on beta for one epoch of mini-batches ------------------------------------------------------
  * update_motion steps the caller's torch.optim.Adam once per mini-batch on the whole (10,3,T) tensor

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_padding(lib):
-    assert lib.dnmf_version() == 1
+    assert lib.dnmf_version() == 2
     assert [lib.dnmf_padded_k(k) for k in (0, 1, 10, 15, 16, 50, 100, 111, 112, 200)] == \
         [0, 16, 16, 16, 32, 64, 112, 112, 128, 208]
 
@@ -55,20 +55,25 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert rc in (-2, -4)  # alignment or workspace, never a launch
     assert lib.dnmf_warp_gram_rhs_workspace(262144, 100, 4000) == 4000 * 3 * 28 * 256 * 4
     # the neuron-list entry points
-    assert lib.dnmf_pack_footprints_lists(addr, 4, 4, 1, 300, addr, addr, addr, addr, None) == -3   # K > 256
-    assert lib.dnmf_pack_footprints_lists(None, 4, 4, 1, 3, addr, addr, addr, addr, None) == -1
-    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 4000) == 4000 * 5 * 461 * 4
-    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, 5000, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr,
-                                      1 << 20, None, None)
+    assert lib.dnmf_pack_footprints_lists(addr, 4, 4, 1, 300, addr, addr, addr, addr, addr, None) == -3   # K > 256
+    assert lib.dnmf_pack_footprints_lists(None, 4, 4, 1, 3, addr, addr, addr, addr, addr, None) == -1
+    assert lib.dnmf_halo_row(512, 1) == 544 and lib.dnmf_halo_row(5, 3) == 32     # rows start on 128-byte lines
+    assert lib.dnmf_halo_voxels(512, 512, 1) == 516 * 544 and lib.dnmf_halo_voxels(4, 5, 3) == 8 * 32
+    assert lib.dnmf_lists_axis_masks_bytes(512, 512, 1, 100) == 2 * (512 + 512 + 1 + 6) * 2 * 8
+    # slot tables (5 chunks per frame at B = 4000; rounded up to 256 bytes), then one 2-word list per frame and tile
+    slab = (4000 * 5 * 461 * 4 + 255) // 256 * 256
+    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 100, 512, 512, 1, 4000) == slab + 4000 * 1024 * 2 * 8
+    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, addr, 5000, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr,
+                                      addr, 1 << 20, None, None)
     assert rc == -3 and b"pattern slots" in lib.dnmf_last_error()
-    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, 10, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr, addr,
-                                      8, None, None)
+    rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, addr, 10, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr,
+                                      addr, 8, None, None)
     assert rc == -4
-    assert lib.dnmf_recon_image_lists(addr, addr, 3, 4, 4, 1, addr, 4, None, 2, addr, 8, None) == -2     # lds < P
+    assert lib.dnmf_recon_image_lists(addr, addr, 3, 4, 4, 1, addr, 4, None, 2, addr, 16, None) == -2    # lds < 8 x 32
     assert lib.dnmf_mu_temporal_nbr(addr, addr, addr, 4, 3, 4, 1, addr, 12, None) == -3                   # NN not 8/16/32
     assert lib.dnmf_adam_epoch_workspace(1000) == 16000
     assert lib.dnmf_adam_epoch(addr, None, addr, addr, 4, 0, addr, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0, addr, 8, None) == -4
-    assert lib.dnmf_warp_recon_grad_workspace(512, 512, 1, 4000) == 4000 * 64 * 32 * 4 + 4000 * 4
+    assert lib.dnmf_warp_recon_grad_workspace(512, 512, 1, 4000) == 512 * 8 + 4000 * 64 * 32 * 4 + 4000 * 4
     # C1: arguments are checked before RCCL is looked up
     assert lib.dnmf_comm_unique_id(None) == -1
     assert lib.dnmf_comm_init(None, addr, 2, 0) == -1

@@ -1,0 +1,323 @@
+"""GPU parity of the path bench.py times (ResidentLoader -> fused Adam epoch + one K2 launch on the cached
+reconstruction images -> K3n -> K4 on the slot tables) and of the BASELINE.json configurations beyond config 1 / 3:
+
+  test_bench_path_*        the bench's chain end to end against fixture G9 / the CPU oracle
+  test_config2_*           256x256, K=50 (configs[1]): forward, Gram data of every Gram kernel, temporal update
+  test_config5_*           512x512, 3 channels, K=200, bf16 (configs[4]) through size-independent properties
+  test_python_log_det_jac  the Python staticmethod against fixture G2's log_det_jac key
+
+Tolerances as in test_gpu_parity.py unless a test says otherwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dnmf_amd.Demix import dNMF
+    return dNMF
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import dnmf_oracle
+    return dnmf_oracle
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def fixed_order_loader(M, frames, sz, bs, epochs):
+    """A ResidentLoader whose epochs use the given mini-batches (list per epoch of lists of frame indices) instead of
+    its own permutation, so that a run can follow the batch order a fixture or the oracle used."""
+    from dnmf_amd import sharding
+
+    class Fixed(M.ResidentLoader):
+        def __init__(self):
+            super().__init__(frames, sz, bs, shuffle=False)
+            self._epochs = [torch.tensor([i for b in ep for i in b]) for ep in epochs]
+            self._next = 0
+
+        def epoch_plan(self):
+            perm = self._epochs[self._next % len(self._epochs)]
+            self._next += 1
+            assert perm.numel() == self.T_total and sorted(perm.tolist()) == list(range(self.T_total))
+            return sharding.plan_epoch(perm, self.batch_size, self.t0, self.t0 + self.T)
+
+    return Fixed()
+
+
+class Calls:
+    """Counts the calls of functions of dnmf_amd.ops while a block runs (which kernels a path really took)."""
+
+    def __init__(self, monkeypatch, *names):
+        from dnmf_amd import ops
+        self.n = {k: 0 for k in names}
+        for k in names:
+            orig = getattr(ops, k)
+
+            def wrapped(*a, _orig=orig, _k=k, **kw):
+                self.n[_k] += 1
+                return _orig(*a, **kw)
+
+            monkeypatch.setattr(ops, k, wrapped)
+
+
+@pytest.mark.parametrize("label", ["lr1e-5_ordered", "lr1e-3_ordered", "lr1e-3_shuffled"])
+def test_bench_path_vs_fixture_G9(M, O, monkeypatch, label):
+    """Fixture G9 (one outer iteration of the reference's demo loop, produced by the reference itself) through the
+    bench's path: resident loader, fused Adam epoch (one K2 launch per group of equal mini-batch size on the cached
+    reconstruction images), neuron-list Gram kernel; same tolerances as the list-loader test of the same fixture."""
+    g = golden("G9_loop")
+    lr, epochs, shuffled, bs = g[label + "_cfg"]
+    bs = int(bs)
+    sz = [int(s) for s in g["sz"]]
+    A = O.gaussian_footprints(g["sz"], g["positions"], np.full(4, 3.0))
+    dn = M.DeformableNMF(torch.from_numpy(g["sz"]), 4, 8, positions=torch.from_numpy(g["positions"]))
+    dn.verbose = False
+    dn.fp.A = dev(A)
+    dn.C = dev(g[label + "_C0"])
+    assert dn.fused_motion and dn.gram_kernel == 'auto'
+    opt = torch.optim.Adam([dn.fp.beta], lr=float(lr))
+    frames = dev(np.moveaxis(g["video"], -1, 0)).reshape(8, -1)
+    order = [[[i for i in b if i >= 0] for b in ep] for ep in g[label + "_order"].tolist()]
+    calls = Calls(monkeypatch, "adam_epoch", "warp_gram_rhs_lists", "recon_image_lists")
+    train = fixed_order_loader(M, frames, sz, bs, order)
+    dn.update_motion(train, opt, gamma=1, epochs=len(order))
+    assert calls.n["adam_epoch"] == 2 * len(order) and calls.n["recon_image_lists"] >= 1   # the fused branch ran
+    ident = O.identity_beta(8)
+    want = g[label + "_beta_after_motion"]
+    scale = np.abs(want - ident).max()
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - ident, want - ident, rtol=0, atol=2e-3 * scale)
+    test = M.ResidentLoader(frames, sz, bs)
+    dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=5, return_dense=False)
+    assert calls.n["warp_gram_rhs_lists"] == 1
+    np.testing.assert_allclose(dn.C.cpu().numpy(), g[label + "_C_after_footprints"], rtol=1e-4)
+
+
+def test_bench_path_vs_oracle_config1(M, O, monkeypatch):
+    """BASELINE configs[0] geometry (64x64, K=10, simulator video), two outer iterations of the demo loop with
+    shuffled mini-batches through the bench's path, against the CPU oracle run on the same batch order -- the
+    resident / fused counterpart of test_gpu_parity.py::test_config1_like_run_vs_oracle, same tolerances."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sz, K, T, bs = [64, 64, 2], 10, 24, 4
+    video, positions, _ = O.generate_video(K, T, sz, 3, .2, -120, {"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    video = np.maximum(video, 0)
+    C0 = torch.rand(K, T)
+    gen = torch.Generator().manual_seed(3)
+    orders = [[torch.randperm(T, generator=gen).tolist() for _ in range(2)] for _ in range(2)]
+    ref = O.OracleModel(sz, K, T, positions[:, :, 0], C0=C0.numpy())
+    ropt = torch.optim.Adam([ref.beta_param], lr=1e-4)
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(positions[:, :, 0]))
+    dn.verbose = False
+    dn.fp.A = dev(ref.A)
+    dn.C = C0.to("cuda")
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-4)
+    frames = dev(np.moveaxis(video, 3, 0)).reshape(T, -1)
+    calls = Calls(monkeypatch, "adam_epoch", "warp_gram_rhs_lists")
+    test = M.ResidentLoader(frames, sz, bs)
+    for outer in range(2):
+        epochs = [[perm[s0:s0 + bs] for s0 in range(0, T, bs)] for perm in orders[outer]]
+        for batches in epochs:
+            ref.update_motion(video, batches, ropt, gamma=1, epochs=1)
+        dn.update_motion(fixed_order_loader(M, frames, sz, bs, epochs), opt, gamma=1, epochs=2)
+        ref.update_footprints(video, bs, gamma_c=0, iter_c=10)
+        dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=10, return_dense=False)
+    assert calls.n["adam_epoch"] == 8 and calls.n["warp_gram_rhs_lists"] == 2
+    ident = O.identity_beta(T)
+    disp = np.abs(ref.beta - ident).max()
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - ident, ref.beta - ident, rtol=0, atol=1e-2 * disp)
+    got, want = dn.C.cpu().numpy(), ref.C
+    calm = want.max(1) < 10   # see test_config1_like_run_vs_oracle: the reference's own update runs away for some rows
+    assert calm.sum() >= 3
+    np.testing.assert_allclose(got[calm], want[calm], rtol=5e-3, atol=1e-6)
+    assert np.all(got[~calm].max(1) > 10)
+
+
+def test_bench_path_slot_tables_vs_oracle(M, O, monkeypatch):
+    """The whole chain of a bench sweep including K4 on the slot tables of K3n (taken when the pattern of G has at
+    most 32 columns per row and K >= 8): compact footprints well inside a 2-D volume, warps that start off the
+    lattice, one sweep = update_motion(epochs=1, shuffled mini-batches) + update_footprints(iter_c=50, gamma_c=0),
+    against the CPU oracle on the same batches.  Off-lattice start and well-conditioned Gram matrices (every
+    footprint inside the volume), so the tolerances are the tight ones: beta 2e-3 of the largest displacement,
+    C rtol 1e-4."""
+    rng = np.random.RandomState(11)
+    sz, K, T, bs = [96, 80, 1], 12, 8, 4
+    pos = np.stack([12 + rng.rand(K) * 72, 12 + rng.rand(K) * 56, np.zeros(K)], 1).astype(np.float32)
+    A = O.gaussian_footprints(sz, pos, np.full(K, 1.3))
+    A[A < 1e-7] = 0
+    Ctrue = 1 + rng.rand(K, T)
+    video = np.einsum("xyzk,kt->xyzt", A.astype(np.float64), Ctrue).astype(np.float32)
+    video += 0.02 * rng.rand(*video.shape).astype(np.float32)
+    C0 = (0.5 + rng.rand(K, T)).astype(np.float32)
+    beta0 = O.identity_beta(T) + (rng.randn(10, 3, T) * np.array([0.4, 3e-3, 3e-3, 0, 3e-5, 3e-5, 0, 3e-5, 0, 0])[:, None, None]
+                                  ).astype(np.float32)
+    beta0[:, 2] = O.identity_beta(T)[:, 2]
+    perm = rng.permutation(T).tolist()
+    batches = [perm[s0:s0 + bs] for s0 in range(0, T, bs)]
+
+    ref = O.OracleModel(sz, K, T, pos, C0=C0)
+    ref.A = A.astype(np.float32)
+    with torch.no_grad():
+        ref.beta_param.copy_(torch.from_numpy(beta0))
+    ropt = torch.optim.Adam([ref.beta_param], lr=1e-3)
+    ref.update_motion(video, batches, ropt, gamma=1, epochs=1)
+    ref.update_footprints(video, bs, gamma_c=0, iter_c=50)
+
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos))
+    dn.verbose = False
+    dn.fp.A = dev(A)
+    dn.C = dev(C0)
+    with torch.no_grad():
+        dn.fp.beta.copy_(dev(beta0))
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+    frames = dev(np.moveaxis(video, 3, 0)).reshape(T, -1)
+    calls = Calls(monkeypatch, "adam_epoch", "warp_gram_rhs_lists", "mu_temporal_slots", "recon_image_lists")
+    dn.update_motion(fixed_order_loader(M, frames, sz, bs, [batches]), opt, gamma=1, epochs=1)
+    dn.update_footprints(M.ResidentLoader(frames, sz, bs), bs, sz, gamma_c=0, iter_c=50, return_dense=False)
+    assert calls.n == {"adam_epoch": 2, "warp_gram_rhs_lists": 1, "mu_temporal_slots": 1, "recon_image_lists": 1}, calls.n
+    disp = np.abs(ref.beta - beta0).max()
+    np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - beta0, ref.beta - beta0, rtol=0, atol=2e-3 * disp)
+    np.testing.assert_allclose(dn.C.cpu().numpy(), ref.C, rtol=1e-4, atol=1e-7)
+
+
+def test_config2_geometry_vs_oracle(M, O):
+    """BASELINE configs[1]: 256x256 (Z=1), K=50, simulator video (device simulator, demo.py's parameters); four frames
+    under non-trivial warps.  forward (K1 + list reconstruction + K2) against the oracle's forward, the Gram data of
+    K3, K3s and K3n against the oracle's float64 contraction, 50 temporal updates against the oracle's."""
+    from dnmf_amd import ops
+    from dnmf_amd.WUtils import Simulator
+    torch.manual_seed(2)
+    np.random.seed(2)
+    sz, K, T = [256, 256, 1], 50, 4
+    frames, positions, _ = Simulator.generate_video_resident(K, T, sz, 3, .2, -120, {"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    frames.clamp_(min=0)
+    pos = positions[:, :, 0].contiguous()
+    rng = np.random.RandomState(2)
+    beta = O.identity_beta(T) + (rng.randn(10, 3, T) * np.array([1.5, 4e-3, 4e-3, 0, 1.5e-5, 1.5e-5, 0, 1.5e-5, 0, 0])[:, None, None]
+                                 ).astype(np.float32)
+    beta[:, 2] = O.identity_beta(T)[:, 2]
+    C = rng.rand(K, T).astype(np.float32)
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    dn.verbose = False
+    fp = dn.fp
+    with torch.no_grad():
+        fp.beta.copy_(dev(beta))
+    A = fp.A.cpu().numpy()
+    lat = O.voxel_lattice(sz)
+    basis = O.quadratic_basis(lat)
+    times = list(range(T))
+    A_tC, A_t, n, reg = O.forward(A, basis, beta, sz, times, C, O.trilinear_sample_torch)
+    gA_tC, gA_t, ggrid, greg = fp(times, torch.from_numpy(C))
+    # coordinates reach 255: their fp32 spacing (1.5e-5) times the steepest footprint slope (0.29 per voxel at sigma 3)
+    np.testing.assert_allclose(gA_t.cpu().numpy(), A_t, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(gA_tC.detach().cpu().numpy(), A_tC, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(ggrid.cpu().numpy(), n, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(greg.cpu().numpy(), reg, rtol=1e-3, atol=1e-7)
+    video = np.ascontiguousarray(np.moveaxis(frames.cpu().numpy().reshape(T, *sz), 0, 3))
+    loss, grad = O.mse_beta_grad_autograd(A, basis, beta, sz, times, C, np.moveaxis(video, -1, 0))
+    gl = torch.nn.functional.mse_loss(gA_tC, frames.view(T, *sz))
+    gl.backward()
+    np.testing.assert_allclose(float(gl), loss, rtol=1e-5)
+    noz = [0, 1, 2, 4, 5, 7]
+    np.testing.assert_allclose(fp.beta.grad.cpu().numpy()[noz][:, :2], grad[noz][:, :2], rtol=1e-4,
+                               atol=1e-4 * np.abs(grad).max())
+    A64 = np.transpose(A_t.astype(np.float64), [2, 3, 4, 1, 0])
+    Gref, rref = O.gram_rhs(A64, video.astype(np.float64))
+    Gref, rref = np.moveaxis(Gref, 2, 0), rref.T
+    order = torch.arange(T, dtype=torch.int32, device="cuda")
+    for kernel in ("dense", "sparse", "lists"):
+        dn.gram_kernel = kernel
+        G, r = dn._gram_rhs(frames, order)
+        np.testing.assert_allclose(G.cpu().numpy(), Gref, rtol=2e-5, atol=2e-5 * np.abs(Gref).max(), err_msg=kernel)
+        np.testing.assert_allclose(r.cpu().numpy(), rref, rtol=2e-5, atol=2e-5 * np.abs(rref).max(), err_msg=kernel)
+    Cref = O.mu_temporal_from_gram(np.moveaxis(Gref, 0, 2), rref.T, C, None, 50)
+    dn.gram_kernel = 'auto'
+    dn.C = dev(C)
+    dn.update_footprints(M.ResidentLoader(frames, sz, 4), 4, sz, gamma_c=0, iter_c=50, return_dense=False)
+    np.testing.assert_allclose(dn.C.cpu().numpy(), Cref, rtol=2e-4, atol=1e-7)
+
+
+def test_config5_geometry_properties(M):
+    """BASELINE configs[4]: three colour channels of a 512x512 volume, K=200, bf16 Gram kernel.  The colour axis has no
+    reference semantics: channels are extra voxels that share beta and C.  At the full geometry the oracle
+    is out of reach, so the checks are size-independent properties: identity warp => G = sum_c colours_c^2 (x) A^T A
+    and r = sum_c A_c^T y_c (float64 products on the GPU); an integer shift => Gram of the shifted footprints; the
+    fp32 path (K3n per channel) against those to 2e-5, the bf16 path (K3b by pairs of neuron groups) to the 1e-2
+    SURVEY 8(c) states; symmetry; a sweep (motion epoch + 50 temporal updates) leaves finite non-negative traces and
+    the bf16 traces within 1e-2 of the fp32 ones."""
+    torch.manual_seed(5)
+    sz, K, T, NC = [512, 512, 1], 200, 4, 3
+    P = 512 * 512
+    pos = torch.rand(K, 3) * torch.tensor([512.0, 512.0, 0.0])
+    colours = 0.3 + torch.rand(NC, K)
+    dn = M.MultiChannelDNMF(torch.tensor(sz), K, T, colours, positions=pos)
+    dn.verbose = False
+    fp = dn.fp
+    with torch.no_grad():
+        fp.beta[0, 0, 1] = 3.0       # frame 1: shift +3 px in x
+    A2 = fp.A.reshape(P, K).double()
+    Ctrue = 1 + torch.rand(K, T, device="cuda")
+    frames = torch.cat([((A2 * colours[c].cuda().double()) @ Ctrue.double()).T.float() for c in range(NC)], 1)   # (T, NC*P)
+    frames += 0.01 * torch.rand_like(frames)
+    order = torch.arange(T, dtype=torch.int32, device="cuda")
+    G0 = sum((A2 * colours[c].cuda().double()).T @ (A2 * colours[c].cuda().double()) for c in range(NC))
+    A3 = fp.A.reshape(512, 512, K)
+    sh = torch.zeros_like(A3)
+    sh[:-3] = A3[3:]
+    S2 = sh.reshape(P, K).double()
+    G1 = sum((S2 * colours[c].cuda().double()).T @ (S2 * colours[c].cuda().double()) for c in range(NC))
+    r0 = sum((A2 * colours[c].cuda().double()).T @ frames[0, c * P:(c + 1) * P].double() for c in range(NC))
+    scale = float(G0.abs().max())
+    res = {}
+    for kernel, tol in (("auto", 2e-5), ("bf16", 1e-2)):
+        dn.gram_kernel = kernel
+        G, r = dn._gram_rhs(frames, order)
+        assert torch.equal(G, G.transpose(1, 2))
+        for t in (0, 2, 3):
+            assert float((G[t].double() - G0).abs().max()) < tol * scale, kernel
+        assert float((G[1].double() - G1).abs().max()) < tol * scale, kernel
+        assert float((r[0].double() - r0).abs().max()) < tol * float(r0.abs().max()), kernel
+        res[kernel] = (G, r)
+    assert float((res["bf16"][0] - res["auto"][0]).abs().max()) < 1e-2 * scale
+    # a sweep through the model on either precision
+    C0 = torch.rand(K, T, device="cuda") + 0.5
+    out = {}
+    for kernel in ("auto", "bf16"):
+        dn.gram_kernel = kernel
+        dn.C = C0.clone()
+        with torch.no_grad():
+            fp.beta.copy_(torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].repeat(1, 1, T))
+        opt = torch.optim.Adam([fp.beta], lr=1e-5)
+        train = M.ResidentLoader(frames, sz, 2, shuffle=True, generator=torch.Generator().manual_seed(0))
+        dn.update_motion(train, opt, gamma=1, epochs=1)
+        dn.update_footprints(M.ResidentLoader(frames, sz, 2), 2, sz, gamma_c=0, iter_c=50)
+        assert bool(torch.isfinite(dn.C).all()) and bool((dn.C >= 0).all())
+        assert bool(torch.isfinite(fp.beta).all())
+        out[kernel] = dn.C.clone()
+    assert float((out["bf16"] - out["auto"]).abs().max()) < 1e-2 * float(out["auto"].abs().max())
+    # the traces move towards the ones the frames were made from
+    assert float((out["auto"] - Ctrue).abs().mean()) < float((C0 - Ctrue).abs().mean())
+
+
+def test_python_log_det_jac(M):
+    """ExponentialFP.log_det_jac (the Python staticmethod the reference exposes, Demix/dNMF.py:107-122) against the
+    values the reference produced for fixture G2 at the far and the near corner of the volume."""
+    g = golden("G2_forward")
+    sz = torch.from_numpy(g["sz"]).float()
+    for i, t in enumerate(g["times"].tolist()):
+        B = torch.from_numpy(g["beta"][:, :, t])
+        got = [float(M.ExponentialFP.log_det_jac(B, sz - 1)), float(M.ExponentialFP.log_det_jac(B, sz * 0))]
+        np.testing.assert_allclose(got, g["log_det_jac"][i], rtol=1e-5, atol=1e-7)
+        Bc = B.cuda()
+        got = [float(M.ExponentialFP.log_det_jac(Bc, (sz - 1).cuda())), float(M.ExponentialFP.log_det_jac(Bc, (sz * 0).cuda()))]
+        np.testing.assert_allclose(got, g["log_det_jac"][i], rtol=1e-5, atol=1e-7)

@@ -18,10 +18,10 @@ def main():
     fp = M.ExponentialFP(torch.tensor(sz), K, T, positions=pos)
     C = torch.rand(K, T, device="cuda")
     times = torch.arange(T, dtype=torch.int32, device="cuda")
-    lds = fp.P
+    lds = ops.halo_voxels(sz)
     S = torch.empty((T, lds), device="cuda")
     ly = fp.packed_lists()
-    for name, fn in (("mfma", lambda: ops.recon_image(fp.packed_footprints(), K, C, times, out=S)),
+    for name, fn in (("mfma", lambda: ops.recon_image(fp.packed_footprints(), K, sz, C, times, out=S)),
                      ("lists", lambda: ops.recon_image_lists(ly, K, sz, C, times, out=S))):
         ms = []
         for _ in range(3):
