@@ -36,6 +36,7 @@ DENSE_RETURN_LIMIT = 1 << 31
 LISTS_BOXFRAC_LIMIT = 6.0   # 'auto' takes K3n below this mean number of footprint boxes per voxel
 RECON_CACHE_LIMIT = 64 << 30
 K2_MAX_FRAMES = 32768       # frames per K2 launch (they ride on gridDim.y)
+STAGE_LIMIT = 96 << 30      # a host loader's frames are staged on the GPU once per pass below this many bytes
 
 
 def _sz_list(sz):
@@ -293,6 +294,10 @@ class DeformableNMF:
         self.group = None
         self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
         self._spatial_buf = None   # A1 (P,K) and C_s (K,K) of spatial_step, one buffer = one all-reduce
+        self._stage_buf = None     # device copy of the frames a host loader served in its last pass
+        self._reg_buf = None       # registered frames (K7) of the last update_footprints(live_spatial=True)
+        self._D_dev = None         # (id(self.D), fp32 device copy of D flattened to (P,K))
+        self.stream_loader = True  # stage host loaders on the GPU once per pass (see _stage_epoch)
         self.time_spatial = False
         self.last_spatial_ms = None
         self._warned = set()
@@ -334,13 +339,14 @@ class DeformableNMF:
         ops.mu_spatial(A_dev, A1.contiguous(), Cs, D_dev, gamma)
         return A_dev.double().cpu().numpy().reshape(A.shape)
 
-    def spatial_step(self, registered, D=None, gamma=None, frame_ids=None):
+    def spatial_step(self, registered, D=None, gamma=None, frame_ids=None, times=None):
         """One multiplicative update of ``fp.A`` from the registered frames this process holds (the update the
         reference leaves commented out at :174, on the flattened voxel axis): K5 on the local frames, ONE all-reduce
         (sum) of the buffer that holds ``A1`` (P,K) and ``C_s`` (K,K) over ``self.group`` when the T axis is sharded,
-        then K6 -- every rank ends with the same footprints.  ``registered`` (T_local,P) fp32 CUDA rows, ``D`` None
-        or (X,Y,Z,K).  ``self.last_spatial_ms`` receives (K5, all-reduce, K6) HIP-event times when
-        ``self.time_spatial`` is set."""
+        then K6 -- every rank ends with the same footprints.  ``registered`` (>=T_local,P) fp32 CUDA rows, frame b in
+        row ``frame_ids[b]`` (None: b) with trace column ``times[b]`` (None: ``frame_ids[b]``, else b); ``D`` None or
+        (X,Y,Z,K).  ``self.last_spatial_ms`` receives (K5, all-reduce, K6) HIP-event times when ``self.time_spatial``
+        is set."""
         fp = self.fp
         P, K = fp.P, fp.K
         C = self.C.to(device, torch.float32).contiguous()
@@ -352,12 +358,14 @@ class DeformableNMF:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_spatial else None
         if ev:
             ev[0].record()
+        if times is None:
+            times = frame_ids
         if K <= 128:
-            ops.spatial_accum(registered, C, frame_ids=frame_ids, times=frame_ids, A1=A1, Cs=Cs, accumulate=False)
+            ops.spatial_accum(registered, C, frame_ids=frame_ids, times=times, A1=A1, Cs=Cs, accumulate=False)
         else:  # K5 holds 8 trace blocks per wave: columns of A1 by groups of 128 neurons; C C^T is tiny
-            Cl = C if frame_ids is None else C[:, torch.as_tensor(frame_ids, device=C.device).long()]
+            Cl = C[:, :registered.shape[0]] if times is None else C[:, torch.as_tensor(times, device=C.device).long()]
             for s0 in range(0, K, 128):
-                part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=frame_ids)
+                part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=times)
                 A1[:, s0:s0 + 128] = part
             Cs.copy_((Cl.double() @ Cl.double().T).float())
         if ev:
@@ -373,7 +381,11 @@ class DeformableNMF:
         if ev:
             ev[2].record()
         A2 = fp.A.reshape(P, K).contiguous()
-        Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(P, K).contiguous()
+        Dd = None
+        if D is not None:   # the fp32 device copy is kept while the caller hands in the same object (105 MB at cfg 3)
+            if self._D_dev is None or self._D_dev[0] is not D:
+                self._D_dev = (D, torch.as_tensor(D).to(device, torch.float32).reshape(P, K).contiguous())
+            Dd = self._D_dev[1]
         ops.mu_spatial(A2, A1, Cs, Dd, gamma)
         fp.A = A2.view(*fp.sz_list, K)
         fp.invalidate_layouts()   # K6 wrote through the raw pointer: the packed copies are stale
@@ -388,19 +400,28 @@ class DeformableNMF:
         """All frames the loader yields, in its order, resident on the GPU as (T,P) plus their indices."""
         if isinstance(loader, ResidentLoader):
             return loader.frames_2d(), loader.order_tensor()
+        staged = self._stage_epoch(loader) if self.stream_loader else None
+        if staged is not None:
+            return staged[0], torch.tensor([t for b in staged[1] for t in b], dtype=torch.int32, device=device)
         fr, idx = [], []
         for data in loader:
             fr.append(data[0].to(device, torch.float32).reshape(data[0].shape[0], -1))
             idx.append(torch.as_tensor(data[1]).to(device, torch.int32).reshape(-1))
         return torch.cat(fr, 0).contiguous(), torch.cat(idx, 0)
 
-    def update_footprints(self, testloader, batch_size, sz, gamma_c=1e-2, gamma_a=1e0, iter_c=10, return_dense=None):
+    def update_footprints(self, testloader, batch_size, sz, gamma_c=1e-2, gamma_a=1e0, iter_c=10, return_dense=None,
+                          live_spatial=False, iter_a=1):
         """Reference :163-179: ``iter_c`` multiplicative updates of ``self.C`` under the current warp.
 
         Returns ``(A_t, Y_i, Y)`` like the reference when the dense float64 ``A_t`` fits
         ``DENSE_RETURN_LIMIT`` (or ``return_dense=True``); otherwise ``(None, None, None)``.
         ``Y_i`` comes from the nearest-neighbour search K7 (``dnmf_image_iwarp``).
-        ``gamma_a`` is unused, as in the reference (its footprint update is commented out, :174)."""
+        ``gamma_a`` is unused unless ``live_spatial`` is set, as in the reference (its footprint update is commented
+        out, :174).  ``live_spatial=True`` (extension) wires that update: after the temporal updates the frames are
+        registered (K7) and ``fp.A`` takes ``iter_a`` multiplicative updates ``A * (Y_i C^T) / (A C C^T + gamma_a D +
+        1e-32)`` (``spatial_step``: K5, one all-reduce over ``self.group``, K6) with the ``D`` of the constructor
+        flattened over the voxels -- the reference's commented lines update an unrelated random ``self.A`` with
+        mismatched shapes (:131, :169-176); here the update acts on the footprints the model uses."""
         fp = self.fp
         K, P = fp.K, fp.P
         with torch.no_grad():
@@ -419,6 +440,13 @@ class DeformableNMF:
             C = self.C.to(device, torch.float32).clone()
             C[:, order.long()] = Cnew
             self.C = C
+            if live_spatial:
+                if self._reg_buf is None or self._reg_buf.shape != (T_loc, P):
+                    self._reg_buf = None
+                    self._reg_buf = torch.empty((T_loc, P), dtype=torch.float32, device=device)
+                ops.image_iwarp(frames, None, fp.sz_list, fp.beta.detach(), order, out=self._reg_buf)
+                for _ in range(iter_a):
+                    self.spatial_step(self._reg_buf, D=self.D, gamma=gamma_a, times=order)
             if return_dense is None:
                 return_dense = 8 * P * K * T_loc <= DENSE_RETURN_LIMIT
             if not return_dense:
@@ -600,48 +628,117 @@ class DeformableNMF:
 
     def update_motion(self, dataloader, optimizer, gamma=0, epochs=20):
         """Reference :181-194: mini-batch steps of the caller's optimiser on ``fp.beta`` against
-        ``mse(A_tC, frames) + gamma*mean(reg)`` (the reg term is gradient-free in the reference, :60-61)."""
+        ``mse(A_tC, frames) + gamma*mean(reg)`` (the reg term is gradient-free in the reference, :60-61).
+
+        A ``ResidentLoader`` hands over rows that already live on the GPU.  Any other loader (the stock
+        ``torch.utils.data.DataLoader`` of demo.py:33-35) is iterated once per epoch by a background thread while this
+        thread copies the mini-batches into a device buffer (``_stage_epoch``); the epoch then runs from that buffer --
+        as four launches when the optimiser is the demo's plain Adam (``_motion_epoch``), else step by step."""
         fp = self.fp
         beta = fp.beta
         S_all = self._recon_cache()
         Cdev = None if S_all is not None else self.C.to(device, torch.float32).contiguous()
         resident = isinstance(dataloader, ResidentLoader)
-        fused = resident and S_all is not None and self._fusable(optimizer)
         for epoch in range(1, epochs + 1):
             if self.verbose:
                 print('Epoch ' + str(epoch))
             fp.train()
-            if fused:
-                self._motion_epoch(dataloader, optimizer, S_all)
+            if resident:
+                plan, frames, rows = dataloader.epoch_plan(), dataloader.frames_2d(), None
+                norms = [min(dataloader.batch_size, dataloader.T_total - j * dataloader.batch_size)
+                         for j in range(plan.nsteps)]
+            else:
+                staged = self._stage_epoch(dataloader) if self.stream_loader else None
+                if staged is None:      # unknown length or too large to stage: batch by batch from the host
+                    self._motion_epoch_from_host(dataloader, optimizer, S_all, Cdev)
+                    continue
+                frames, batch_times = staged
+                plan = sharding.plan_from_batches(batch_times, fp.T)
+                norms = [len(b) for b in batch_times]
+                # row of the staging buffer that holds frame t
+                flat = torch.tensor([t for b in batch_times for t in b], dtype=torch.int64)
+                rows = torch.zeros(fp.T, dtype=torch.int32)
+                rows[flat] = torch.arange(flat.numel(), dtype=torch.int32)
+                rows = rows.to(device)
+                if plan is None:        # a frame served twice in one epoch: the steps as they come
+                    plan = sharding.EpochPlan(len(batch_times), None, None, None, [torch.tensor(b, dtype=torch.int64)
+                                                                                   for b in batch_times])
+            if plan.frame_step is not None and S_all is not None and self._fusable(optimizer):
+                self._motion_epoch(plan, frames, rows, optimizer, S_all)
                 continue
-            for batch_idx, (times, frames, frame_ids, norm) in enumerate(self._iter_batches(dataloader, resident)):
+            for batch_idx, b in enumerate(plan.batches):
                 optimizer.zero_grad()
                 if beta.grad is None:
                     beta.grad = torch.zeros_like(beta)
-                if times.numel() == 0:      # sharded: this global mini-batch has no frame here; still a step
+                if b.numel() == 0:      # sharded: this global mini-batch has no frame here; still a step
                     optimizer.step()
                     continue
+                times = b.to(device, torch.int32)
                 want = self.verbose and batch_idx % 10 == 0
-                out = self._k2(S_all, Cdev, frames, frame_ids, times, beta.grad, norm, want)
+                out = self._k2(S_all, Cdev, frames, times if rows is None else rows[times.long()], times, beta.grad,
+                               norms[batch_idx], want)
                 optimizer.step()
                 if want:
                     print('Recon: ' + str(out["loss"][0]))
                     print('Reg: ' + str(out["reg"]))
 
+    def _motion_epoch_from_host(self, dataloader, optimizer, S_all, Cdev):
+        """One epoch with every mini-batch copied from the host when it is needed (loaders that cannot be staged)."""
+        beta = self.fp.beta
+        for batch_idx, data in enumerate(dataloader):
+            times = torch.as_tensor(data[1]).to(device, torch.int32).reshape(-1)
+            frames = data[0].to(device, torch.float32).reshape(times.numel(), -1)
+            optimizer.zero_grad()
+            if beta.grad is None:
+                beta.grad = torch.zeros_like(beta)
+            want = self.verbose and batch_idx % 10 == 0
+            out = self._k2(S_all, Cdev, frames, None, times, beta.grad, 0, want)
+            optimizer.step()
+            if want:
+                print('Recon: ' + str(out["loss"][0]))
+                print('Reg: ' + str(out["reg"]))
+
     @staticmethod
-    def _iter_batches(dataloader, resident):
-        """(frame indices int32 on the GPU, frames (B,P) or the resident (T,P) rows, row ids or None, frames the
-        loss mean runs over) for every mini-batch of one epoch."""
-        if resident:
-            plan = dataloader.epoch_plan()
-            for j, b in enumerate(plan.batches):
-                size = min(dataloader.batch_size, dataloader.T_total - j * dataloader.batch_size)
-                idx = b.to(device, torch.int32)
-                yield idx, dataloader.frames_2d(), idx, size
-        else:
-            for data in dataloader:
-                times = torch.as_tensor(data[1]).to(device, torch.int32).reshape(-1)
-                yield times, data[0].to(device, torch.float32).reshape(times.numel(), -1), None, 0
+    def _loader_frames(loader):
+        """Frames one pass over ``loader`` yields, or None when that cannot be told without iterating it."""
+        sampler = getattr(loader, "sampler", None)
+        if getattr(loader, "dataset", None) is not None and sampler is not None and hasattr(sampler, "__len__") \
+                and getattr(loader, "batch_size", None):
+            n = len(sampler)
+            return n // loader.batch_size * loader.batch_size if getattr(loader, "drop_last", False) else n
+        if isinstance(loader, (list, tuple)):
+            return sum(len(d[1]) for d in loader)
+        return None
+
+    def _stage_epoch(self, loader):
+        """One pass over a host loader into a device buffer: returns ``(frames (n, row) fp32 CUDA rows in arrival
+        order, [frame indices of every mini-batch])``, or None when the number of frames is unknown or the buffer would
+        exceed ``STAGE_LIMIT``.  The loader is iterated by a background thread (its collate copies overlap the
+        host-to-device copies issued here; pinned batches -- ``DataLoader(pin_memory=True)`` -- are copied
+        asynchronously), and the buffer is kept between calls."""
+        n = self._loader_frames(loader)
+        row = sum(f.P for f, _ in self._channels())
+        if n is None or n == 0 or 4 * n * row > STAGE_LIMIT:
+            return None
+        if self._stage_buf is None or self._stage_buf.shape[0] < n or self._stage_buf.shape[1] != row:
+            self._stage_buf = None
+            self._stage_buf = torch.empty((n, row), dtype=torch.float32, device=device)
+        buf = self._stage_buf
+        batch_times, at = [], 0
+        for data in _Prefetch(loader):
+            idx = data[1].tolist() if hasattr(data[1], "tolist") else [int(i) for i in data[1]]
+            if isinstance(idx, int):
+                idx = [idx]
+            B = len(idx)
+            if at + B > n:
+                raise RuntimeError(f"the loader yielded more than the {n} frames its length announces")
+            src = data[0].reshape(B, -1)
+            if src.shape[1] != row:
+                raise ValueError(f"a frame has {src.shape[1]} values, the model expects {row}")
+            buf[at:at + B].copy_(src, non_blocking=src.is_pinned() if hasattr(src, "is_pinned") else False)
+            batch_times.append(idx)
+            at += B
+        return buf[:at], batch_times
 
     def _fusable(self, optimizer):
         """True when ``optimizer`` is exactly the reference demo's: torch.optim.Adam([fp.beta]) without
@@ -654,10 +751,11 @@ class DeformableNMF:
         return not (g.get('amsgrad') or g.get('maximize') or g.get('weight_decay', 0) != 0 or g.get('capturable')
                     or g.get('differentiable') or g.get('fused') or g.get('decoupled_weight_decay'))
 
-    def _motion_epoch(self, loader, optimizer, S_all):
+    def _motion_epoch(self, plan, frames, rows, optimizer, S_all):
         """One epoch of mini-batch Adam steps in four launches (dnmf_adam_epoch phase 0, K2 over all frames,
-        phase 1).  The optimiser's own state tensors are read and written, so the caller's optimiser stays
-        valid and a later un-fused step continues from it."""
+        phase 1).  ``plan``: the epoch's EpochPlan; ``frames`` (n, row) device rows, frame t in row ``rows[t]``
+        (``rows`` None: in row t).  The optimiser's own state tensors are read and written, so the caller's optimiser
+        stays valid and a later un-fused step continues from it."""
         fp, beta = self.fp, self.fp.beta
         g = optimizer.param_groups[0]
         state = optimizer.state[beta]
@@ -665,7 +763,6 @@ class DeformableNMF:
             state['step'] = torch.tensor(0.0, dtype=torch.get_default_dtype())
             state['exp_avg'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
             state['exp_avg_sq'] = torch.zeros_like(beta, memory_format=torch.preserve_format)
-        plan = loader.epoch_plan()
         n = plan.nsteps
         step0 = int(state['step'])
         args = (step0, plan.frame_step.to(device), n, g['lr'], g['betas'], g['eps'])
@@ -678,7 +775,7 @@ class DeformableNMF:
                 if idx.numel() == 0:
                     continue
                 idx = idx.to(device, torch.int32)
-                out = self._k2(S_all, None, loader.frames_2d(), idx, idx, grad, nf, self.verbose)
+                out = self._k2(S_all, None, frames, idx if rows is None else rows[idx.long()], idx, grad, nf, self.verbose)
                 outs.append((idx, nf, out))
             ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1, order=order)
         state['step'] += n
@@ -689,12 +786,15 @@ class DeformableNMF:
                 print('Recon: ' + str(out["frame_loss"][j * nf:(j + 1) * nf].sum()))
                 print('Reg: ' + str(out["reg"][j * nf:(j + 1) * nf]))
 
-    def fit(self, dataloader, testloader, optimizer, batch_size, outer=5, gamma=1, epochs=10, gamma_c=0, iter_c=50):
-        """Convenience wrapper of the loop ``demo.py:44-46`` writes out (not part of the reference)."""
+    def fit(self, dataloader, testloader, optimizer, batch_size, outer=5, gamma=1, epochs=10, gamma_c=0, iter_c=50,
+            spatial=False, gamma_a=1e0):
+        """Convenience wrapper of the loop ``demo.py:44-46`` writes out (not part of the reference).  ``spatial=True``
+        also updates the footprints after every temporal update (``update_footprints(live_spatial=True)``)."""
         out = (None, None, None)
         for _ in range(outer):
             self.update_motion(dataloader, optimizer, gamma=gamma, epochs=epochs)
-            out = self.update_footprints(testloader, batch_size, self.fp.sz_list, gamma_c=gamma_c, iter_c=iter_c)
+            out = self.update_footprints(testloader, batch_size, self.fp.sz_list, gamma_c=gamma_c, gamma_a=gamma_a,
+                                         iter_c=iter_c, live_spatial=spatial)
         return out
 
 
@@ -771,6 +871,53 @@ def _mu_temporal(G, r, C, gamma, iters, group=None, nbr=None):
     return a.to(C.dtype)
 
 
+class _Prefetch:
+    """Iterates ``loader`` in a background thread, two items ahead: the loader's own work (indexing the dataset,
+    collating a mini-batch: host memory copies that release the GIL) overlaps what the consumer does with the
+    previous item.  Exceptions of the loader are re-raised in the consumer."""
+
+    _END = object()
+
+    def __init__(self, loader, depth=2):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=depth)
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, args=(loader,), daemon=True)
+        self._thread.start()
+
+    def _put(self, item):
+        import queue
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                pass
+
+    def _run(self, loader):
+        try:
+            for item in loader:
+                self._put(item)
+                if self._stop:
+                    return
+            self._put(self._END)
+        except BaseException as exc:  # noqa: BLE001 - handed to the consumer
+            self._put(exc)
+
+    def __iter__(self):
+        try:
+            while True:
+                item = self._q.get()
+                if item is self._END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            self._stop = True
+
+
 class ResidentLoader:
     """Iterates mini-batches of a video that already lives on the GPU as (T,P) rows.
 
@@ -832,6 +979,9 @@ class SimulatedVideoDataset(Dataset):
         else:
             video, positions, traces = Simulator.generate_video(K, T, _sz_list(sz), shape_std, density, bg_snr, traces,
                                                                 motion, motion_par)
+            # same values and the reference's (X,Y,Z,T) shape, but frame-major in memory: ``video[..., t]`` is then
+            # one contiguous block instead of P floats that lie T apart (a cache line each)
+            video = video.float().permute(3, 0, 1, 2).contiguous().permute(1, 2, 3, 0)
         self.video = video.float()
         self.positions = positions
         self.traces = traces

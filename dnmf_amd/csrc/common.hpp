@@ -51,33 +51,52 @@ struct Sample {
 };
 
 // The warped coordinate q_d = sum_a basis_a(x,y,z) * beta[a][d], basis order [1,x,y,z,x^2,y^2,z^2,xy,xz,yz]
-// (Demix/dNMF.py:46-51,54), evaluated grouped by powers of x:
-//   a_d(x) = 2 q_d = c[0] + c[1] x + c[2] x^2,   c[0] = 2 (b0 + b2 y + b5 y^2 [+ b3 z + b6 z^2 + b9 yz]),
-//                                               c[1] = 2 (b1 + b7 y [+ b8 z]),   c[2] = 2 b4
-// so that a thread that walks along x with (y,z) fixed pays two FMAs per coordinate and voxel.  The reference forms
-// the same polynomial with an fp32 einsum (a BLAS product whose summation order is not specified); any order agrees
-// with it to rounding, and EVERY kernel of this library uses this one, so their coordinates agree bit for bit.  The
-// factor 2 of the normalisation (dNMF.py:55) is folded into the coefficients: scaling by a power of two is exact.
-// At the identity (b1 = e_x, b2 = e_y, b3 = e_z, rest 0) a_d is exactly twice the voxel coordinate (products with
-// an exact 0 or 1 and sums with an exact 0 only), which is what the on-lattice floor() decisions rest on.
-// `b` points at 30 floats laid out [a*3 + d].  HASZ = false is Z == 1 (z = 0: the terms with z are exact zeros).
+// (Demix/dNMF.py:46-51,54).  The reference forms it with an fp32 einsum, i.e. a BLAS product over the ten basis
+// terms; torch's CPU path accumulates them in index order with fused multiply-adds starting from zero, and the chain
+// below is that sequence, bit for bit (checked on 10^5 voxels under random and under Adam-stepped coefficients: 100 %
+// equal; a regrouping by powers of x, two FMAs per coordinate cheaper, agrees on 55 %).  That matters where a
+// coordinate lands on a lattice point -- at the identity, and again on whole curves of voxels after the first Adam
+// step, which moves every coefficient by exactly the learning rate: there floor() turns on the last bit.
+//
+// The monomials are fp32 products like the reference's basis tensor (dNMF.py:48-50); a thread that walks along x with
+// (y,z) fixed keeps y^2, z^2, yz.  poly_a returns a_d = 2 q_d from DOUBLED coefficients (double_beta): scaling the
+// coefficients by a power of two scales every partial sum exactly, and 2 q is what the normalisation needs
+// (dNMF.py:55).  `b2` points at 30 floats laid out [a*3 + d].  HASZ = false is Z == 1 (z = 0: the four terms with z
+// add an exact zero each for finite coefficients and are left out).
 template <bool HASZ>
-__device__ __forceinline__ void poly_coeffs(const float *b, int d, float y, float z, float (&c)[3]) {
-    float c0 = fmaf(b[6 + d], y, b[0 + d]);
-    c0 = fmaf(b[15 + d], __fmul_rn(y, y), c0);
-    float c1 = fmaf(b[21 + d], y, b[3 + d]);
-    if (HASZ) {
-        c0 = fmaf(b[9 + d], z, c0);
-        c0 = fmaf(b[18 + d], __fmul_rn(z, z), c0);
-        c0 = fmaf(b[27 + d], __fmul_rn(y, z), c0);
-        c1 = fmaf(b[24 + d], z, c1);
-    }
-    c[0] = __fmul_rn(2.0f, c0), c[1] = __fmul_rn(2.0f, c1), c[2] = __fmul_rn(2.0f, b[12 + d]);
+struct Monomials {
+    float x, y, z, xx, yy, zz, xy, xz, yz;
+};
+
+template <bool HASZ>
+__device__ __forceinline__ Monomials<HASZ> monomials(float x, float y, float z) {
+    Monomials<HASZ> m;
+    m.x = x, m.y = y, m.z = HASZ ? z : 0.0f;
+    m.xx = __fmul_rn(x, x), m.yy = __fmul_rn(y, y), m.xy = __fmul_rn(x, y);
+    m.zz = HASZ ? __fmul_rn(z, z) : 0.0f, m.xz = HASZ ? __fmul_rn(x, z) : 0.0f, m.yz = HASZ ? __fmul_rn(y, z) : 0.0f;
+    return m;
 }
 
-// a_d at x; xx = RN(x * x)
-__device__ __forceinline__ float poly_a(const float (&c)[3], float x, float xx) {
-    return fmaf(c[2], xx, fmaf(c[1], x, c[0]));
+__device__ __forceinline__ void double_beta(const float *b, float *b2) {
+#pragma unroll
+    for (int i = 0; i < 30; ++i) b2[i] = __fmul_rn(2.0f, b[i]);
+}
+
+template <bool HASZ>
+__device__ __forceinline__ float poly_a(const float *b2, int d, const Monomials<HASZ> &m) {
+    float q = b2[0 + d];                 // fma(1, b0, 0)
+    q = fmaf(m.x, b2[3 + d], q);
+    q = fmaf(m.y, b2[6 + d], q);
+    if (HASZ) q = fmaf(m.z, b2[9 + d], q);
+    q = fmaf(m.xx, b2[12 + d], q);
+    q = fmaf(m.yy, b2[15 + d], q);
+    if (HASZ) q = fmaf(m.zz, b2[18 + d], q);
+    q = fmaf(m.xy, b2[21 + d], q);
+    if (HASZ) {
+        q = fmaf(m.xz, b2[24 + d], q);
+        q = fmaf(m.yz, b2[27 + d], q);
+    }
+    return q;
 }
 
 // clamp into [0, n-1] in one instruction (v_med3_i32)
@@ -114,12 +133,26 @@ __device__ __forceinline__ float normalise_axis(float a, const Volume &vol, int 
     return vol.fastdiv ? normalise_fast(a, sm1, rcp) : normalise(a, sm1);
 }
 
-// n of voxel (x,y,z) along axis d, everything from scratch (kernels that do not walk along x)
+// n of voxel (x,y,z) along axis d, everything from scratch (kernels that do not walk along x); `b` = beta as stored
 template <bool HASZ, int FAST = -1>
 __device__ __forceinline__ float grid_n(const float *b, const Volume &vol, int d, float x, float y, float z) {
-    float c[3];
-    poly_coeffs<HASZ>(b, d, y, z, c);
-    return normalise_axis<FAST>(poly_a(c, x, __fmul_rn(x, x)), vol, d);
+    const Monomials<HASZ> m = monomials<HASZ>(x, y, z);
+    const float b2[10] = {__fmul_rn(2.0f, b[d]),      __fmul_rn(2.0f, b[3 + d]),  __fmul_rn(2.0f, b[6 + d]),  __fmul_rn(2.0f, b[9 + d]),
+                          __fmul_rn(2.0f, b[12 + d]), __fmul_rn(2.0f, b[15 + d]), __fmul_rn(2.0f, b[18 + d]), __fmul_rn(2.0f, b[21 + d]),
+                          __fmul_rn(2.0f, b[24 + d]), __fmul_rn(2.0f, b[27 + d])};
+    float q = b2[0];
+    q = fmaf(m.x, b2[1], q);
+    q = fmaf(m.y, b2[2], q);
+    if (HASZ) q = fmaf(m.z, b2[3], q);
+    q = fmaf(m.xx, b2[4], q);
+    q = fmaf(m.yy, b2[5], q);
+    if (HASZ) q = fmaf(m.zz, b2[6], q);
+    q = fmaf(m.xy, b2[7], q);
+    if (HASZ) {
+        q = fmaf(m.xz, b2[8], q);
+        q = fmaf(m.yz, b2[9], q);
+    }
+    return normalise_axis<FAST>(q, vol, d);
 }
 
 // torch grid_sampler_unnormalize, align_corners=True: ((n + 1) / 2) * (S - 1) in fp32 without contraction, as

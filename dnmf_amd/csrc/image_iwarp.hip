@@ -56,18 +56,23 @@ __device__ double iwarp_min_stretch(const float *b, const Volume &vol) {
             hx += 4 * b4 * b4 + b7 * b7, hy += b7 * b7 + 4 * b5 * b5;
         }
     }
-    double smin;
+    // two lower bounds of the smallest singular value at the centre: 1 - |J - I|_F (Weyl; tight for the near-identity
+    // warps of a fit) and |det| over the product of the other singular values (any warp)
+    double off = 0, fro = 0;
+    for (int d = 0; d < nd; ++d)
+        for (int e = 0; e < nd; ++e) {
+            const double v = J[d][e] - (d == e ? 1.0 : 0.0);
+            off += v * v, fro += J[d][e] * J[d][e];
+        }
+    double smin = 1.0 - sqrt(off);
     if (hz) {
         const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
                            J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-        double fro = 0;
-        for (int d = 0; d < 3; ++d)
-            for (int e = 0; e < 3; ++e) fro += J[d][e] * J[d][e];
-        smin = fabs(det) / (0.5 * fro);   // sigma_3 = |det| / (sigma_1 sigma_2), sigma_1 sigma_2 <= |J|_F^2 / 2
+        smin = fmax(smin, fabs(det) / (0.5 * fro));   // sigma_3 = |det| / (sigma_1 sigma_2), sigma_1 sigma_2 <= |J|_F^2 / 2
     } else {
         const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        const double fro = J[0][0] * J[0][0] + J[0][1] * J[0][1] + J[1][0] * J[1][0] + J[1][1] * J[1][1];
-        smin = fabs(det) / sqrt(fro);     // sigma_2 = |det| / sigma_1, sigma_1 <= |J|_F
+        const double disc = fmax(fro * fro - 4.0 * det * det, 0.0);
+        smin = fmax(smin, sqrt(fmax(0.5 * (fro - sqrt(disc)), 0.0)) * (1.0 - 1e-9));   // exact for a 2 x 2 matrix
     }
     const double drift = cx * sqrt(hx) + cy * sqrt(hy) + cz * sqrt(hzz);
     const double m = 0.98 * (smin - drift);
@@ -100,13 +105,11 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
     float vx = gx * kx, vy = gy * ky, vz = hz ? gz * kz : 0.0f;
     for (int it = 0; it < 4; ++it) {
         float s[3] = {0.0f, 0.0f, 0.0f};
+        float b2[30];
+        double_beta(bt, b2);
         for (int d = 0; d < (hz ? 3 : 2); ++d) {
-            float c[3];
-            if (hz)
-                poly_coeffs<true>(bt, d, vy, vz, c);
-            else
-                poly_coeffs<false>(bt, d, vy, 0.0f, c);
-            s[d] = 0.5f * poly_a(c, vx, vx * vx) / (d == 0 ? kx : (d == 1 ? ky : kz));   // q S/(S-1)
+            const float a = hz ? poly_a<true>(b2, d, monomials<true>(vx, vy, vz)) : poly_a<false>(b2, d, monomials<false>(vx, vy, 0.0f));
+            s[d] = 0.5f * a / (d == 0 ? kx : (d == 1 ? ky : kz));   // q S/(S-1)
         }
         vx += (gx - s[0]) * kx, vy += (gy - s[1]) * ky;
         if (hz) vz += (gz - s[2]) * kz;

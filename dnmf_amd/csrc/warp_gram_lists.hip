@@ -22,8 +22,8 @@
 //     under the same map).  Pairs outside the pattern are never accumulated and come out as 0.
 //
 // Data flow.  Lane = voxel (16 lanes along y: the neuron-major footprint copy At is read in coalesced 64-byte
-// runs), four voxels per lane along x; tiles are walked along x, so a lane's (y,z) and with them the coefficients
-// of its coordinate polynomials in x change only at the end of a tile row.  At is in the halo layout of common.hpp:
+// runs), four voxels per lane along x; tiles are walked along x, so a lane's (y,z) and the monomials without x
+// change only at the end of a tile row.  At is in the halo layout of common.hpp:
 // a tap outside the volume reads a zero, no masks or clamps along x and y.  Per listed neuron: 2 x NTAP/2 eight-byte
 // loads and NTAP FMAs per voxel give its warped values a_k, then r_k += a_k.y and G_kl += a_k.a_l for the listed
 // l >= k as per-lane partial sums.  While consecutive tiles have the same list the partial sums stay in registers;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void lists_axis_masks_kernel(const int *__rest
     }
 }
 
-// Conservative range of a_d = 2 q_d (poly_coeffs) over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0:
+// Conservative range of a_d = 2 q_d over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0:
 // every monomial is monotone there, so a term's range follows from the sign of its coefficient.
 __device__ __forceinline__ void poly_range(const float *b, int d, const float (&lo)[3], const float (&hi)[3], bool hasz,
                                            float &amin, float &amax) {
@@ -191,7 +191,6 @@ template <int NTAP, int NW, int FAST, bool F32OFF>
 __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     extern __shared__ float s_tab[];
     constexpr bool HASZ = NTAP == 8;
-    constexpr int ND = HASZ ? 3 : 2;
     constexpr int NPAIR = LISTS_NG * (LISTS_NG + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -289,8 +288,10 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         run_n = 0;
     };
 
-    float c[ND][3];
-    int row_of_c = -1;  // the tile row (qy, qz) the coefficients belong to
+    float b2[30];
+    double_beta(bt, b2);
+    Monomials<HASZ> mono = monomials<HASZ>(0.0f, 0.0f, 0.0f);
+    int row_of_c = -1;  // the tile row (qy, qz) `mono` belongs to
     unsigned long long prev[NW];
 #pragma unroll
     for (int wd = 0; wd < NW; ++wd) prev[wd] = 0;
@@ -315,9 +316,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         const int qx = q % p.ntx, rest = q / p.ntx;
         if (rest != row_of_c) {
             const int qz = rest % p.ntz, qy = rest / p.ntz;
-            const float yf = (float)((qy << 4) + ly), zf = (float)((qz << lgz) + lz);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) poly_coeffs<HASZ>(bt, d, yf, zf, c[d]);
+            mono = monomials<HASZ>(0.0f, (float)((qy << 4) + ly), (float)((qz << lgz) + lz));
             row_of_c = rest;
         }
         const int qz = rest % p.ntz, qy = rest / p.ntz;
@@ -339,11 +338,13 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
 #pragma unroll
             for (int v = 0; v < LISTS_VPL; ++v) {
                 const int x = xt + (v << lgx) + lx;
-                const float xf = x0f + (float)(v << lgx), xx = __fmul_rn(xf, xf);
+                Monomials<HASZ> m = mono;
+                m.x = x0f + (float)(v << lgx), m.xx = __fmul_rn(m.x, m.x), m.xy = __fmul_rn(m.x, m.y);
+                if (HASZ) m.xz = __fmul_rn(m.x, m.z);
                 float fx, fy, wx[2], wy[2];
-                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[0], xf, xx), vol, 0), vol.hx1), hl.xhi, fx, wx[0],
+                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 0, m), vol, 0), vol.hx1), hl.xhi, fx, wx[0],
                                wx[1]);
-                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[1], xf, xx), vol, 1), vol.hy1), hl.yhi, fy, wy[0],
+                axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 1, m), vol, 1), vol.hy1), hl.yhi, fy, wy[0],
                                wy[1]);
                 const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);
                 float wzm[2] = {1.0f, 0.0f};
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
                 if (HASZ) {
                     int iz;
                     float wz[2];
-                    axis_weights(unnormalise(normalise_axis<FAST>(poly_a(c[ND - 1], xf, xx), vol, 2), vol.hz1), iz, wz[0], wz[1]);
+                    axis_weights(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1), iz, wz[0], wz[1]);
 #pragma unroll
                     for (int dz = 0; dz < 2; ++dz) {
                         wzm[dz] = in_range(iz + dz, vol.Z) ? wz[dz] : 0.0f;

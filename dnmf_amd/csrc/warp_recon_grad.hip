@@ -32,8 +32,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Work layout: a block owns 16 x-rows by 256 consecutive positions of the (y,z) plane (lane = position, so the frame
 // and the reconstruction image are read in 256-byte runs and the taps of neighbouring lanes share cache lines); a
-// thread walks down its 16 rows with (y,z) fixed, so its warped coordinates are quadratics in x with per-thread
-// coefficients (poly_coeffs) and x, x^2 are the same for the whole block: they come from a table (scalar loads).
+// thread walks down its 16 rows with (y,z) fixed: the monomials without x are per-thread constants, and x, x^2 are the
+// same for the whole block: they come from a table (scalar loads).  The polynomial itself is the reference's chain of
+// ten (six for Z = 1) fused multiply-adds, in its order (common.hpp: poly_a).
 //
 // S carries the zero halo of common.hpp around x and y: a tap outside the volume reads a zero instead of being
 // masked, for the value and for the gradient alike (grid_sample's backward skips out-of-bounds corners: it adds the
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     const float yf = (float)yy, zf = (float)z;
 
     if (u < YZ) {
-        float c[ND][3];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) poly_coeffs<HASZ>(bt, d, yf, zf, c[d]);
+        float b2[30];
+        double_beta(bt, b2);
+        Monomials<HASZ> mono = monomials<HASZ>(0.0f, yf, zf);   // y, z, y^2, z^2, yz: fixed along the rows
         const int x_first = bx * K2_ROWS;
         const int nrow = min(K2_ROWS, vol.X - x_first);
 
@@ -100,17 +101,19 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
         auto request = [&](int x, Req &q) {
             q.xv = xtab[x];                   // a scalar load
             q.prow = (long)x * YZ;            // block-uniform: (scalar base + 32-bit lane offset) accesses
+            Monomials<HASZ> m = mono;
+            m.x = q.xv.x, m.xx = q.xv.y, m.xy = __fmul_rn(q.xv.x, yf);
+            if (HASZ) m.xz = __fmul_rn(q.xv.x, zf);
             float fx, fy;
-            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[0], q.xv.x, q.xv.y), vol, 0), vol.hx1), hl.xhi, fx,
-                           q.wx[0], q.wx[1]);
-            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a(c[1], q.xv.x, q.xv.y), vol, 1), vol.hy1), hl.yhi, fy,
-                           q.wy[0], q.wy[1]);
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 0, m), vol, 0), vol.hx1), hl.xhi, fx, q.wx[0],
+                           q.wx[1]);
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 1, m), vol, 1), vol.hy1), hl.yhi, fy, q.wy[0],
+                           q.wy[1]);
             const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);   // base corner, slice 0
             int iz = 0;
             if (HASZ) {
                 float wz[2];
-                axis_weights(unnormalise(normalise_axis<FAST>(poly_a(c[ND - 1], q.xv.x, q.xv.y), vol, 2), vol.hz1), iz, wz[0],
-                             wz[1]);
+                axis_weights(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1), iz, wz[0], wz[1]);
 #pragma unroll
                 for (int dz = 0; dz < 2; ++dz) {
                     const bool zin = in_range(iz + dz, vol.Z);

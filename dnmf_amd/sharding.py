@@ -67,6 +67,25 @@ def plan_epoch(perm: torch.Tensor, batch_size: int, t0: int, t1: int) -> EpochPl
                      batches=_LazySplit(torch.from_numpy(local), counts))
 
 
+def plan_from_batches(batches, T_local: int):
+    """The EpochPlan of an epoch whose mini-batches are given explicitly (what a stock DataLoader served): ``batches``
+    is a list of lists of LOCAL frame indices, one per optimiser step, of any sizes.  Returns None when a frame occurs
+    more than once in the epoch (the per-column form of the Adam epoch then does not apply)."""
+    nsteps = len(batches)
+    flat = np.fromiter((i for b in batches for i in b), dtype=np.int64)
+    if flat.size == 0 or np.unique(flat).size != flat.size or flat.min() < 0 or flat.max() >= T_local:
+        return None
+    sizes_per_batch = np.fromiter((len(b) for b in batches), dtype=np.int64, count=nsteps)
+    steps = np.repeat(np.arange(nsteps, dtype=np.int64), sizes_per_batch)
+    frame_step = np.full((T_local,), -1, dtype=np.int32)
+    frame_step[flat] = steps.astype(np.int32)
+    sizes = sizes_per_batch[steps]
+    groups = [(torch.from_numpy(flat[sizes == s]), int(s)) for s in sorted(set(sizes_per_batch.tolist()), reverse=True) if s > 0]
+    order = np.argsort(frame_step, kind="stable").astype(np.int32)
+    return EpochPlan(nsteps=nsteps, frame_step=torch.from_numpy(frame_step), order=torch.from_numpy(order), groups=groups,
+                     batches=_LazySplit(torch.from_numpy(flat), sizes_per_batch.tolist()))
+
+
 class _LazySplit:
     """``list(torch.split(local, counts))`` built on first use: the fused epoch never looks at it."""
 

@@ -50,6 +50,57 @@ print("rank", rank, "ok")
 '''
 
 
+NCCL_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from dnmf_amd import sharding
+from dnmf_amd.Demix import dNMF as M
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+world = dist.get_world_size()
+torch.manual_seed(5)
+rng = np.random.RandomState(5)
+sz, K, T, bs = [24, 20, 2], 6, 12, 4
+pos = torch.from_numpy(rng.rand(K, 3) * np.array(sz)).float()
+frames = torch.rand(T, sz[0] * sz[1] * sz[2]).cuda()
+C0 = torch.rand(K, T)
+
+def run(t0, t1, group):
+    dn = M.DeformableNMF(torch.tensor(sz), K, t1 - t0, positions=pos)
+    dn.verbose, dn.group = False, group
+    dn.C = C0[:, t0:t1].cuda().contiguous()
+    A = dn.spatial_step(frames[t0:t1], D=torch.rand(*sz, K, generator=torch.Generator().manual_seed(1)), gamma=0.3)
+    return A.clone(), dn
+
+t0, t1 = sharding.shard_bounds(T, world, rank)
+A_s, dn = run(t0, t1, dist.group.WORLD)       # ONE dnmf_allreduce_sum_f32 (RCCL) of the packed A1 | C_s buffer
+assert dn._comm is not None and dn._comm.nranks == world
+A_f, _ = run(0, T, None)
+assert torch.allclose(A_s, A_f, rtol=2e-5, atol=1e-30), float(((A_s - A_f).abs() / (A_f.abs() + 1e-30)).max())
+dn._comm.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_ranks_rccl(tmp_path):
+    """The same spatial update over the library's own RCCL communicator, one GPU per rank: runs where two GPUs are
+    visible (the driver's multi-GPU node), skips on the one-GPU test box."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "worker_nccl.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29521", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("ok") == 2
+
+
 def test_two_ranks_on_one_gpu(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

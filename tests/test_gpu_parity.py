@@ -242,14 +242,19 @@ def test_registered_video_window_search_equals_exhaustive(M, O, sz):
     assert torch.equal(out[:, :-5], ref) and bool((out[:, -5:] == -1.0).all())
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("label", ["lr1e-5_ordered", "lr1e-3_ordered", "lr1e-3_shuffled"])
-def test_G9_demo_loop(M, O, label):
+def test_G9_demo_loop(M, O, label, fused):
+    """Fixture G9 with host loaders (lists of (frames, indices), as a DataLoader yields them): ``fused`` = the epoch
+    staged on the GPU and evaluated by the per-column Adam kernel, else one K2 launch and one ``optimizer.step()`` of
+    torch per mini-batch."""
     g = golden("G9_loop")
     lr, epochs, shuffled, bs = g[label + "_cfg"]
     bs = int(bs)
     A = O.gaussian_footprints(g["sz"], g["positions"], np.full(4, 3.0))
     dn = M.DeformableNMF(torch.from_numpy(g["sz"]), 4, 8, positions=torch.from_numpy(g["positions"]))
     dn.verbose = False
+    dn.fused_motion = fused
     dn.fp.A = dev(A)
     dn.C = dev(g[label + "_C0"])
     opt = torch.optim.Adam([dn.fp.beta], lr=float(lr))

@@ -162,3 +162,25 @@ def test_G10_z1_semantics():
     for _ in range(5):
         Cc = O.update_temporal(A_t64, Cc, g["Y2d"][:, :, None, :].astype(np.float64), gamma=0)
     np.testing.assert_allclose(Cc, g["C_it5"], rtol=1e-5)
+
+
+def test_reference_polynomial_is_the_index_order_fma_chain():
+    """The HIP kernels evaluate the warped coordinate as the chain of fused multiply-adds over the ten basis terms in
+    index order (csrc/common.hpp: poly_a).  That is what torch's CPU einsum -- the reference's Demix/dNMF.py:54 --
+    computes, bit for bit; pinned here so that a torch build with another accumulation order shows up as a failure of
+    THIS test rather than as unexplained last-bit differences at lattice coincidences."""
+    import torch
+    rng = np.random.RandomState(0)
+    for sz in ([20, 16, 2], [50, 50, 2], [64, 64, 1]):
+        lat = O.voxel_lattice(sz)
+        basis = O.quadratic_basis(lat)
+        T = 4
+        beta = O.identity_beta(T) + (rng.randn(10, 3, T) * np.array([0.7] + [1e-2] * 3 + [2e-4] * 6)[:, None, None]).astype(np.float32)
+        beta[:, :, 0] = O.identity_beta(1)[:, :, 0] + np.float32(1e-3) * np.sign(rng.randn(10, 3)).astype(np.float32)  # one Adam step
+        q = torch.einsum("mnza,abt->mnzbt", torch.from_numpy(basis), torch.from_numpy(beta)).numpy()
+        B = basis.reshape(-1, 10)
+        chain = np.zeros((B.shape[0], 3, T), np.float32)
+        for a in range(10):   # fma emulated in float64: the product of two fp32 numbers is exact there
+            chain = (B[:, a][:, None, None].astype(np.float64) * beta[a][None].astype(np.float64) + chain.astype(np.float64)
+                     ).astype(np.float32)
+        assert np.array_equal(q, chain.reshape(q.shape))
