@@ -12,9 +12,18 @@ T=4000, K=100, fp32.  N>1: the T axis is sharded, every rank holds 4000 frames o
 (weak scaling); there is no data-path collective (frames are independent in both steps), only the timing
 barrier.  The video is generated on the GPU before the timed region starts (inputs resident in HBM).
 
+``--with-spatial`` adds the footprint update the reference leaves commented out (Demix/dNMF.py:169-176) to every
+sweep: K7 registration, K5, ONE all-reduce of the A1 | C_s buffer over the ranks (RCCL for N > 1) and K6 -- the only
+collective the path has; it is a separate mode, never the headline value.
+
 Rank 0 prints ONE JSON line; it also carries
   roofline      the dominant kernel (the Gram kernel K3n / K3s / K3) timed with HIP events on its stream
   cpu_baseline  the CPU oracle (reference op sequence) timed on this host on a bounded sample, N=1 only
+  extras        (default N=1 run only, outside the timed region, a few sweeps each; --no-extras skips them)
+                depth2: the same sweep at 512x512x2 -- the smallest volume the reference itself can run, 8-tap kernels;
+                with_spatial: the sweep of --with-spatial with its kernel times;
+                stock_dataloader: the sweep driven by a plain torch DataLoader over a HOST video as in demo.py:33-35
+                (configs[1] whole, a 400-frame subset of configs[2]): PCIe- and host-inclusive frames/s
 """
 import argparse
 import json
@@ -24,6 +33,7 @@ import time
 
 import numpy as np
 import torch
+import torch.utils.data
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,23 +58,35 @@ def parse():
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--gram", choices=["auto", "dense", "sparse", "lists"], default="auto",
                     help="Gram kernel: K3 (dense), K3s (exact-zero blocks skipped), K3n (neuron lists) or by footprint shape")
+    ap.add_argument("--depth", type=int, default=1, help="Z (slices); the headline workload is Z = 1")
+    ap.add_argument("--with-spatial", action="store_true",
+                    help="sweep = default + update_footprints(live_spatial=True): K7 registration, K5, ONE all-reduce of "
+                         "A1 | C_s over the ranks (RCCL for N > 1), K6 -- the path's only collective")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements of the default N=1 run (Z = 2 line, spatial mode, stock DataLoader)")
     return ap.parse_args()
 
 
-def other_kernels(evs, P, K, T_loc, tjson, key):
-    """HBM rooflines of the two other kernels of a sweep that move data, from the same HIP-event hooks."""
+def other_kernels(evs, P, K, T_loc, tjson, key, Pp):
+    """HBM rooflines of the two other kernels of a sweep that move data, from the same HIP-event hooks.  Pp = floats of
+    a reconstruction image in the halo layout (what is actually written / addressed)."""
     out = []
+    mg = evs("motion_grad_lists")
+    if mg:
+        ms = 1e3 * sum(mg) / len(mg)
+        b = 12.0 * P * T_loc   # the frame read, the reconstruction image written and read back
+        out.append({"kernel": "dnmf_motion_grad_lists: recon_lists_kernel + warp_recon_grad_kernel (K2) + its finish kernel, "
+                              "alternating over pieces of frames whose reconstruction images share one cache-resident buffer",
+                    "bound": "hbm", "launch_ms": ms, "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                    "count": "algorithmic bytes 12PT = frame 4PT + reconstruction image written 4PT and gathered 4PT; the "
+                             "image traffic is meant to stay in the Infinity Cache, so HBM should see ~4PT (traffic)",
+                    "traffic": tjson.get(f"{key.split('_K')[0]}_motion")})
     k2 = evs("warp_recon_grad")
-    if k2:
-        ms = 1e3 * sum(k2) / len(k2)
-        b = 8.0 * P * T_loc   # the reconstruction image and the frame, once each
-        out.append({"kernel": "warp_recon_grad_kernel (K2, incl. its finish kernel)", "bound": "hbm", "launch_ms": ms,
-                    "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": b / ms / 1e6 / HBM_PEAK_GBS, "traffic": tjson.get(f"{key.split('_K')[0]}_K2")})
     rl = evs("recon_image_lists")
     if rl:
         ms = 1e3 * sum(rl) / len(rl)
-        b = 4.0 * P * T_loc   # the reconstruction image, written once
+        b = 4.0 * P * T_loc   # the reconstruction image, written once (algorithmic; the halo layout adds Pp/P - 1)
         out.append({"kernel": "recon_lists_kernel (reconstruction image from neuron lists)", "bound": "hbm",
                     "launch_ms": ms, "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,
@@ -132,6 +154,105 @@ def cpu_baseline(size, K, batch, iter_c, positions0, frames_host):
     }
 
 
+class HostVideo(torch.utils.data.Dataset):
+    """A host copy of the video behind the reference's dataset protocol (Demix/dNMF.py:196-217): frame-major memory,
+    the (X,Y,Z,T) shape as a view, __getitem__ -> (frame, index) with the in-place clamp."""
+
+    def __init__(self, frames, sz):
+        self.video = frames.view(frames.shape[0], *sz).permute(1, 2, 3, 0)
+
+    def __len__(self):
+        return self.video.shape[3]
+
+    def __getitem__(self, idx):
+        sample = self.video[:, :, :, idx]
+        sample[sample < 0] = 0
+        return sample, idx
+
+
+def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spatial=False, loader="resident"):
+    """Build the workload (synthetic video resident in HBM, model, loaders) and time `steps` sweeps after `warmup`.
+    loader = "resident": the fit reads the rows where they lie; "dataloader": a stock torch DataLoader over a host
+    copy of the video (demo.py:33-35), every sweep crosses PCIe twice.  Returns a dict of measurements."""
+    from dnmf_amd import ops
+    from dnmf_amd.Demix import dNMF as M
+    from dnmf_amd.WUtils import Simulator
+    bs = args.batch
+    T_total = T_loc * world
+    torch.manual_seed(0)
+    np.random.seed(0)
+    par = {"sigma": [5, 5, .01], "ls": [10, 10, 10]}
+    frames, positions, _ = Simulator.generate_video_resident(K, T_total, sz, 3, .2, -120, par, t0=rank * T_loc,
+                                                             t1=(rank + 1) * T_loc, group=group)
+    frames.clamp_(min=0)  # what the dataset's __getitem__ does to every frame it serves (dNMF.py:214-215)
+    positions0 = positions[:, :, 0].contiguous()
+    torch.manual_seed(1 + rank)
+    dn = M.DeformableNMF(torch.tensor(sz), K, T_loc, positions=positions0)
+    dn.verbose = False
+    dn.gram_kernel = args.gram
+    dn.group = group
+    opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
+    if loader == "resident":
+        # every rank draws the SAME global mini-batch order and keeps its own frames: the optimiser-step sequence
+        # is the single-process one for the 4000*N-frame video (dnmf_amd/sharding.py)
+        gen = torch.Generator().manual_seed(1234)
+        train = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=gen, t0=rank * T_loc, T_total=T_total)
+        test = M.ResidentLoader(frames, sz, bs, shuffle=False)
+    else:
+        host = HostVideo(frames.cpu(), sz)
+        del frames
+        frames = None
+        train = torch.utils.data.DataLoader(host, batch_size=bs, shuffle=True, generator=torch.Generator().manual_seed(1234))
+        test = torch.utils.data.DataLoader(host, batch_size=bs, shuffle=False)
+
+    def step():
+        dn.update_motion(train, opt, gamma=1, epochs=1)
+        dn.update_footprints(test, bs, sz, gamma_c=0, gamma_a=1.0, iter_c=args.iter_c, return_dense=False,
+                             live_spatial=with_spatial)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ops.TIMING = {}           # hooks on during warm-up too: their first use has one-time costs (event pool, counters)
+    for _ in range(max(1, warmup)):
+        step()
+    fence()
+    ops.TIMING = {}
+    for counters in (ops.SPARSE_COUNTERS, ops.LISTS_COUNTERS):
+        if counters is not None:
+            counters.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing, ops.TIMING = ops.TIMING, None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    lists_counters = None if ops.LISTS_COUNTERS is None else ops.LISTS_COUNTERS.tolist()
+    sparse_counters = None if ops.SPARSE_COUNTERS is None else ops.SPARSE_COUNTERS.tolist()
+
+    def evs(name):
+        return [a.elapsed_time(b) * 1e-3 for a, b in timing.get(name, [])]
+
+    per_step = {name: 1e3 * sum(evs(name)) / steps for name in timing}
+    return {"elapsed": elapsed, "evs": evs, "per_step_ms": per_step, "dn": dn, "frames": frames, "positions0": positions0,
+            "lists_counters": lists_counters, "sparse_counters": sparse_counters, "T_total": T_total}
+
+
+def short_line(res, steps):
+    """frames/s, ms per sweep and the per-kernel HIP-event times of a secondary measurement."""
+    return {"value": res["T_total"] * steps / res["elapsed"], "unit": "frames/s", "steps": steps,
+            "ms_per_step": 1e3 * res["elapsed"] / steps,
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())}}
+
+
 def main():
     args = parse()
     # torch sizes its CPU thread pool by the host's core count; under a smaller cgroup quota every CPU op then gets
@@ -154,70 +275,20 @@ def main():
         group = dist.group.WORLD
 
     from dnmf_amd import ops
-    from dnmf_amd.Demix import dNMF as M
-    from dnmf_amd.WUtils import Simulator
 
-    size, K, T_loc, bs = args.size, args.neurons, args.frames, args.batch
-    sz = [size, size, 1]
-    P = size * size
+    size, K, T_loc, bs, Z = args.size, args.neurons, args.frames, args.batch, args.depth
+    sz = [size, size, Z]
+    P = size * size * Z
     T_total = T_loc * world
+    ntap = 8 if Z > 1 else 4
 
-    # ---- synthetic input, resident in HBM (demo.py:26-28 parameters) ---------------------------------
-    torch.manual_seed(0)
-    np.random.seed(0)
-    par = {"sigma": [5, 5, .01], "ls": [10, 10, 10]}
-    frames, positions, _ = Simulator.generate_video_resident(K, T_total, sz, 3, .2, -120, par, t0=rank * T_loc,
-                                                             t1=(rank + 1) * T_loc, group=group)
-    frames.clamp_(min=0)  # what the dataset's __getitem__ does to every frame it serves (dNMF.py:214-215)
-    positions0 = positions[:, :, 0].contiguous()
-
-    torch.manual_seed(1 + rank)
-    dn = M.DeformableNMF(torch.tensor(sz), K, T_loc, positions=positions0)
-    dn.verbose = False
-    dn.gram_kernel = args.gram
-    opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
-    # every rank draws the SAME global mini-batch order and keeps its own frames: the optimiser-step sequence
-    # is the single-process one for the 4000*N-frame video (dnmf_amd/sharding.py)
-    gen = torch.Generator().manual_seed(1234)
-    train = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=gen, t0=rank * T_loc, T_total=T_total)
-    test = M.ResidentLoader(frames, sz, bs, shuffle=False)
-
-    def step():
-        dn.update_motion(train, opt, gamma=1, epochs=1)
-        dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=args.iter_c, return_dense=False)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    ops.TIMING = {}           # hooks on during warm-up too: their first use has one-time costs (event pool, counters)
-    for _ in range(max(1, args.warmup) if args.warmup else 0):
-        step()
-    if not args.warmup and K <= 127:  # still pay the one-time costs outside the timed region
-        ops.warp_gram_rhs(dn.fp.packed_footprints(), K, sz, dn.fp.beta.detach(), [0], frames)
-    fence()
-    ops.TIMING = {}
-    for counters in (ops.SPARSE_COUNTERS, ops.LISTS_COUNTERS):
-        if counters is not None:
-            counters.zero_()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timing, ops.TIMING = ops.TIMING, None
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
+    res = run_sweeps(args, sz, K, T_loc, args.steps, args.warmup, rank, world, group, with_spatial=args.with_spatial)
+    elapsed, evs, dn, frames, positions0 = res["elapsed"], res["evs"], res["dn"], res["frames"], res["positions0"]
 
     # one launch of the dense Gram kernel outside the timed region, for the roofline of the kernel that
     # evaluates every product (the timed sweeps may have used the zero-skipping kernel instead)
     dense_ms = None
-    if rank == 0 and K <= 127:  # one K3 launch holds at most 127 neurons
+    if rank == 0 and K <= 127 and not args.no_extras:  # one K3 launch holds at most 127 neurons
         torch.cuda.synchronize()
         ops.TIMING = {}
         ops.warp_gram_rhs(dn.fp.packed_footprints(), K, sz, dn.fp.beta.detach(), None, frames)
@@ -225,46 +296,46 @@ def main():
         (a, b), = ops.TIMING["warp_gram_rhs"]
         dense_ms, ops.TIMING = a.elapsed_time(b), None
 
+    line = None
     if rank == 0:
-        def evs(name):
-            return [a.elapsed_time(b) * 1e-3 for a, b in timing.get(name, [])]
         k3d, k3s, k3n, k2 = (evs("warp_gram_rhs"), evs("warp_gram_rhs_sparse"), evs("warp_gram_rhs_lists"),
                              evs("warp_recon_grad"))
         lists, sparse = len(k3n) > 0, len(k3s) > 0
         k3 = k3n if lists else (k3s if sparse else k3d)
         k3_avg = sum(k3) / max(1, len(k3))
         # algorithmic flops of one Gram launch when every product is evaluated (symmetric Gram,
-        # rhs, 4 bilinear taps)
-        dense_flops = T_loc * (P * K * (K + 1) + 2 * P * K + 8 * P * K)
+        # rhs, 4 or 8 interpolation taps)
+        dense_flops = T_loc * (P * K * (K + 1) + 2 * P * K + 2 * ntap * P * K)
         tjson = {}
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             tjson = json.load(open(tpath))
-        key = f"{size}x{size}x{T_loc}_K{K}"
+        key = f"{size}x{size}x{T_loc}_K{K}" if Z == 1 else f"{size}x{size}x{Z}x{T_loc}_K{K}"
         if lists:
             # K3n has no matrix-pipe work; its floor is the traffic it cannot avoid: every frame once, the footprints
             # once (they stay in L2 / MALL across frames), G and r once
             abytes = 4.0 * P * T_loc + 4.0 * P * K + 4.0 * T_loc * (K * K + K)
-            n_eval, n_pair = (float(v) / len(k3n) for v in ops.LISTS_COUNTERS.tolist())
-            roof = {"kernel": "warp_gram_lists_kernel<4,2> (K3n: per 256-voxel tile only the neurons whose non-zero box "
-                              "the tile's taps reach; vector ALU, no MFMA)",
+            n_eval, n_pair = (float(v) / len(k3n) for v in res["lists_counters"])
+            roof = {"kernel": f"warp_gram_lists_kernel<{ntap},{1 if K <= 64 else 2 if K <= 128 else 4},1,true> (K3n: per "
+                              "256-voxel tile only the neurons whose non-zero box the tile's taps can reach; vector ALU, no "
+                              "MFMA) + lists_tilemask_kernel (the tiles' neuron lists), one API call",
                     "bound": "hbm", "achieved": abytes / k3_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": abytes / k3_avg / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(key + "_lists"),
                     "launch_ms": 1e3 * k3_avg, "launches": len(k3n), "bytes_per_launch": abytes,
                     "count": "algorithmic bytes = frames 4PT + footprints 4PK (once per launch) + G, r 4T(K^2+K); the "
-                             "kernel is bound by vector-ALU issue of the reference's fp32 coordinate sequence (~140 "
-                             "instructions per voxel, evaluated once per voxel), see valu_issue",
+                             "kernel is bound by vector-ALU issue (the reference's fp32 coordinate sequence once per voxel "
+                             "and frame, then gathers and reductions per listed neuron), see valu_issue",
                     "valu_issue": tjson.get(key + "_lists_valu"),
                     "tile_neuron_evaluations_per_launch": n_eval, "tile_pair_sums_per_launch": n_pair,
                     "dense_equivalent_flops_per_launch": dense_flops,
                     "dense_equivalent_tflops": dense_flops / k3_avg / 1e12}
         elif sparse:
             # flops of the products that were not skipped, from the kernel's own counters: an MFMA is
-            # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (4 taps + rhs) FMAs
-            n_mfma, n_blend = (float(v) / len(k3s) for v in ops.SPARSE_COUNTERS.tolist())
-            flops = n_mfma * 2048 + n_blend * 64 * 2 * 5 + T_loc * P * 82  # + warp geometry (82 flops/voxel)
+            # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (taps + rhs) FMAs
+            n_mfma, n_blend = (float(v) / len(k3s) for v in res["sparse_counters"])
+            flops = n_mfma * 2048 + n_blend * 64 * 2 * (ntap + 1) + T_loc * P * 82  # + warp geometry (82 flops/voxel)
             kname = "warp_gram_lt_kernel" if ops.SPARSE_VARIANT == "table" else "warp_gram_sparse_kernel"
-            roof = {"kernel": kname + "<7,4> (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",
+            roof = {"kernel": kname + " (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",
                     "bound": "mfma", "achieved": flops / k3_avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": tjson.get(key + "_sparse"),
                     "launch_ms": 1e3 * k3_avg, "launches": len(k3s), "flops_per_launch": flops,
@@ -275,11 +346,11 @@ def main():
                     "dense_equivalent_flops_per_launch": dense_flops,
                     "dense_equivalent_tflops": dense_flops / k3_avg / 1e12}
         else:
-            roof = {"kernel": "warp_gram_kernel<7,4> (K3, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
+            roof = {"kernel": "warp_gram_kernel (K3, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
                     "achieved": dense_flops / k3_avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": dense_flops / k3_avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": tjson.get(key),
                     "launch_ms": 1e3 * k3_avg, "launches": len(k3), "flops_per_launch": dense_flops,
-                    "count": "P*K*(K+1) symmetric Gram + 2PK rhs + 8PK bilinear taps, per frame"}
+                    "count": "P*K*(K+1) symmetric Gram + 2PK rhs + 2*taps*PK interpolation, per frame"}
         line = {
             "metric": "frames/sec demixed, 512x512xT K=100",
             "value": T_total * args.steps / elapsed,
@@ -288,22 +359,55 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Simulator {size}x{size}x{T_total} (Z=1), K={K}, fp32: update_motion(epochs=1, "
-                                   f"batch {bs}, Adam lr 1e-5) + update_footprints(iter_c={args.iter_c}, gamma_c=0)",
-                       "frames_per_gpu": T_loc, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+            "config": {"workload": f"Simulator {size}x{size}x{T_total} (Z={Z}), K={K}, fp32: update_motion(epochs=1, "
+                                   f"batch {bs}, Adam lr 1e-5) + update_footprints(iter_c={args.iter_c}, gamma_c=0"
+                                   + (", live_spatial=True: K7 + K5 + all-reduce + K6)" if args.with_spatial else ")"),
+                       "frames_per_gpu": T_loc,
+                       "parallelism": f"frames sharded over {world} GPU(s), " +
+                                      ("one RCCL all-reduce of A1 | C_s per sweep" if args.with_spatial else "no collective"),
                        "gram_kernel": dn.gram_kernel + (" -> neuron lists (K3n)" if lists else
                                                         " -> zero-skipping blocks (K3s)" if sparse else " -> dense (K3)")},
             "roofline": roof,
             "roofline_dense_kernel": None if dense_ms is None else {
-                "kernel": "warp_gram_kernel<7,4> (K3): every product evaluated, one launch outside the timed region",
+                "kernel": "warp_gram_kernel (K3): every product evaluated, one launch outside the timed region",
                 "bound": "mfma", "achieved": dense_flops / (dense_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": dense_flops / (dense_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "traffic": tjson.get(key), "launch_ms": dense_ms, "flops_per_launch": dense_flops},
-            "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps, "K2_motion_kernels": 1e3 * sum(k2) / args.steps},
-            "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key),
+            "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps,
+                                      "K2_motion_kernels": 1e3 * (sum(k2) + sum(evs("motion_grad_lists"))) / args.steps},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())},
+            "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key, ops.halo_voxels(sz)),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and Z == 1:
             line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy())
+
+    # ---- secondary measurements (N = 1, default workload): never part of `value` -----------------------------------
+    if world == 1 and not args.no_extras and not args.with_spatial and Z == 1 and size == 512 and K == 100:
+        del res, dn, frames
+        torch.cuda.empty_cache()
+        extras = {}
+        # the smallest volume the reference itself can run has two slices (Demix/dNMF.py:55 divides by Z-1)
+        r2 = run_sweeps(args, [size, size, 2], K, T_loc, 5, 2, 0, 1, None)
+        extras["depth2"] = dict(short_line(r2, 5), workload=f"{size}x{size}x2x{T_loc}, K={K}: the 8-tap kernel variants")
+        del r2
+        torch.cuda.empty_cache()
+        # the footprint update the reference leaves commented out, wired in (K7 registration + K5 + K6)
+        r3 = run_sweeps(args, sz, K, T_loc, 3, 1, 0, 1, None, with_spatial=True)
+        extras["with_spatial"] = dict(short_line(r3, 3), workload="the default sweep + update_footprints(live_spatial=True)")
+        del r3
+        torch.cuda.empty_cache()
+        # what demo.py really drives: a stock DataLoader over a host video (PCIe-inclusive, host-bound)
+        dl = {}
+        for name, s2, K2, T2 in (("config2_256x256x1000_K50", 256, 50, 1000), ("config3_subset_512x512x400_K100", 512, 100, 400)):
+            r4 = run_sweeps(args, [s2, s2, 1], K2, T2, 2, 1, 0, 1, None, loader="dataloader")
+            dl[name] = short_line(r4, 2)
+            del r4
+            torch.cuda.empty_cache()
+        extras["stock_dataloader"] = dict(dl, note="torch.utils.data.DataLoader(batch 4, shuffle, num_workers=0) over a host "
+                                                   "copy of the video, as demo.py:33-35; every sweep serves the video twice "
+                                                   "from the host (update_motion, update_footprints)")
+        line["extras"] = extras
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -294,12 +294,14 @@ class DeformableNMF:
         self.group = None
         self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
         self._spatial_buf = None   # A1 (P,K) and C_s (K,K) of spatial_step, one buffer = one all-reduce
+        self._ws_mg = None
+        # frames per piece of the fused motion epoch on compact footprints: a piece's reconstruction images (1.1 MB each
+        # at 512x512) and its frames must fit the 256 MB Infinity Cache together; 0 = all frames at once through HBM
+        self.motion_chunk = 64
         self._stage_buf = None     # device copy of the frames a host loader served in its last pass
         self._reg_buf = None       # registered frames (K7) of the last update_footprints(live_spatial=True)
         self._D_dev = None         # (id(self.D), fp32 device copy of D flattened to (P,K))
         self.stream_loader = True  # stage host loaders on the GPU once per pass (see _stage_epoch)
-        self.time_spatial = False
-        self.last_spatial_ms = None
         self._warned = set()
 
     # ---- static NMF updates (numpy in / numpy out like the reference) ---------------------------------
@@ -355,9 +357,6 @@ class DeformableNMF:
             self._spatial_buf = torch.empty((P * K + K * K,), dtype=torch.float32, device=device)
         buf = self._spatial_buf
         A1, Cs = buf[:P * K].view(P, K), buf[P * K:].view(K, K)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_spatial else None
-        if ev:
-            ev[0].record()
         if times is None:
             times = frame_ids
         if K <= 128:
@@ -368,8 +367,6 @@ class DeformableNMF:
                 part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=times)
                 A1[:, s0:s0 + 128] = part
             Cs.copy_((Cl.double() @ Cl.double().T).float())
-        if ev:
-            ev[1].record()
         if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
             if torch.distributed.get_backend(self.group) == "nccl":
                 # one process per GPU: the library's own RCCL communicator (C1), built on first use
@@ -377,9 +374,8 @@ class DeformableNMF:
                     self._comm = ops.Communicator(self.group)
                 self._comm.all_reduce_(buf)
             else:  # ranks that share a card or run without one (gloo rehearsal): RCCL cannot span them
-                torch.distributed.all_reduce(buf, group=self.group)
-        if ev:
-            ev[2].record()
+                with ops._timed("allreduce"):
+                    torch.distributed.all_reduce(buf, group=self.group)
         A2 = fp.A.reshape(P, K).contiguous()
         Dd = None
         if D is not None:   # the fp32 device copy is kept while the caller hands in the same object (105 MB at cfg 3)
@@ -389,10 +385,6 @@ class DeformableNMF:
         ops.mu_spatial(A2, A1, Cs, Dd, gamma)
         fp.A = A2.view(*fp.sz_list, K)
         fp.invalidate_layouts()   # K6 wrote through the raw pointer: the packed copies are stale
-        if ev:
-            ev[3].record()
-            torch.cuda.synchronize()
-            self.last_spatial_ms = tuple(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
         return fp.A
 
     # ---- fit steps -------------------------------------------------------------------------------------
@@ -636,8 +628,17 @@ class DeformableNMF:
         as four launches when the optimiser is the demo's plain Adam (``_motion_epoch``), else step by step."""
         fp = self.fp
         beta = fp.beta
-        S_all = self._recon_cache()
-        Cdev = None if S_all is not None else self.C.to(device, torch.float32).contiguous()
+        # reconstruction images of all frames (C is constant inside this call): built when first needed -- the fused
+        # epoch on compact footprints makes its own, chunk by chunk (_motion_epoch)
+        cache = {}
+
+        def recon():
+            if not cache:
+                cache["S"] = self._recon_cache()
+                cache["C"] = None if cache["S"] is not None else self.C.to(device, torch.float32).contiguous()
+            return cache["S"], cache["C"]
+
+        chunked = self.motion_chunk > 0 and self._motion_lists_layout() is not None
         resident = isinstance(dataloader, ResidentLoader)
         for epoch in range(1, epochs + 1):
             if self.verbose:
@@ -650,7 +651,7 @@ class DeformableNMF:
             else:
                 staged = self._stage_epoch(dataloader) if self.stream_loader else None
                 if staged is None:      # unknown length or too large to stage: batch by batch from the host
-                    self._motion_epoch_from_host(dataloader, optimizer, S_all, Cdev)
+                    self._motion_epoch_from_host(dataloader, optimizer, *recon())
                     continue
                 frames, batch_times = staged
                 plan = sharding.plan_from_batches(batch_times, fp.T)
@@ -663,9 +664,10 @@ class DeformableNMF:
                 if plan is None:        # a frame served twice in one epoch: the steps as they come
                     plan = sharding.EpochPlan(len(batch_times), None, None, None, [torch.tensor(b, dtype=torch.int64)
                                                                                    for b in batch_times])
-            if plan.frame_step is not None and S_all is not None and self._fusable(optimizer):
-                self._motion_epoch(plan, frames, rows, optimizer, S_all)
+            if plan.frame_step is not None and self._fusable(optimizer) and (chunked or recon()[0] is not None):
+                self._motion_epoch(plan, frames, rows, optimizer, None if chunked else recon()[0])
                 continue
+            S_all, Cdev = recon()
             for batch_idx, b in enumerate(plan.batches):
                 optimizer.zero_grad()
                 if beta.grad is None:
@@ -751,11 +753,23 @@ class DeformableNMF:
         return not (g.get('amsgrad') or g.get('maximize') or g.get('weight_decay', 0) != 0 or g.get('capturable')
                     or g.get('differentiable') or g.get('fused') or g.get('decoupled_weight_decay'))
 
+    def _motion_lists_layout(self):
+        """The K3n layout when the motion gradient can take its reconstruction images from the neuron lists (one
+        channel, compact footprints); else None."""
+        fp = self.fp
+        if len(self._channels()) != 1 or not fp.use_lists or fp.K > 256:
+            return None
+        ly = fp.packed_lists()
+        return ly if ly["boxfrac"] < LISTS_BOXFRAC_LIMIT else None
+
     def _motion_epoch(self, plan, frames, rows, optimizer, S_all):
-        """One epoch of mini-batch Adam steps in four launches (dnmf_adam_epoch phase 0, K2 over all frames,
-        phase 1).  ``plan``: the epoch's EpochPlan; ``frames`` (n, row) device rows, frame t in row ``rows[t]``
-        (``rows`` None: in row t).  The optimiser's own state tensors are read and written, so the caller's optimiser
-        stays valid and a later un-fused step continues from it."""
+        """One epoch of mini-batch Adam steps: dnmf_adam_epoch phase 0, the gradient of every frame at its coasted
+        beta, phase 1.  ``plan``: the epoch's EpochPlan; ``frames`` (n, row) device rows, frame t in row ``rows[t]``
+        (``rows`` None: in row t).  ``S_all`` None: compact footprints, the reconstruction images are made
+        ``motion_chunk`` frames at a time right before K2 gathers from them (``dnmf_motion_grad_lists``: they stay in
+        the Infinity Cache); else the cached images of all frames and one K2 launch per group of equal mini-batch
+        size.  The optimiser's own state tensors are read and written, so the caller's optimiser stays valid and a
+        later un-fused step continues from it."""
         fp, beta = self.fp, self.fp.beta
         g = optimizer.param_groups[0]
         state = optimizer.state[beta]
@@ -771,11 +785,19 @@ class DeformableNMF:
             ops.adam_epoch(beta, None, state['exp_avg'], state['exp_avg_sq'], *args, phase=0, order=order)
             grad = torch.zeros_like(beta)
             outs = []
+            Cdev = self.C.to(device, torch.float32).contiguous() if S_all is None else None
             for idx, nf in plan.groups:
                 if idx.numel() == 0:
                     continue
                 idx = idx.to(device, torch.int32)
-                out = self._k2(S_all, None, frames, idx if rows is None else rows[idx.long()], idx, grad, nf, self.verbose)
+                fid = idx if rows is None else rows[idx.long()]
+                if S_all is None:
+                    out = ops.motion_grad_lists(self._motion_lists_layout(), fp.K, fp.sz_list, Cdev, frames, fid,
+                                                beta.detach(), idx, grad, nf, self.motion_chunk, want=self.verbose,
+                                                workspace=self._ws_mg)
+                    self._ws_mg = out["workspace"]
+                else:
+                    out = self._k2(S_all, None, frames, fid, idx, grad, nf, self.verbose)
                 outs.append((idx, nf, out))
             ops.adam_epoch(beta, grad, state['exp_avg'], state['exp_avg_sq'], *args, phase=1, order=order)
         state['step'] += n

@@ -170,6 +170,35 @@ def warp_recon_grad(S, s_ids, frames, frame_ids, sz, beta, times, grad=None, gou
     return {"recon": recon, "loss": loss, "frame_loss": frame_loss, "reg": reg, "workspace": workspace}
 
 
+def motion_grad_lists(layout, K, sz, C, frames, frame_ids, beta, times, grad, norm_frames, chunk, want=False, workspace=None):
+    """The motion gradient of the frames ``times`` from the K3n layout: list reconstruction and K2 alternate over pieces
+    of ``chunk`` frames whose images share one buffer (they stay in the Infinity Cache).  ``grad`` (10,3,T) is
+    incremented.  Returns dict(frame_loss, reg, workspace) (the first two None unless ``want``)."""
+    X, Y, Z = (int(s) for s in sz)
+    dev = beta.device
+    _f32(beta, "beta"), _f32(C, "C"), _f32(grad, "grad")
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("motion_grad_lists: frames must be float32 CUDA with unit inner stride")
+    tt = _i32(times, dev)
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = tt.numel()
+    lib = _lib.load()
+    chunk = max(1, min(int(chunk), B))
+    need = lib.dnmf_motion_grad_lists_workspace(X, Y, Z, chunk)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    frame_loss = torch.empty((B,), dtype=torch.float32, device=dev) if want else None
+    reg = torch.empty((B,), dtype=torch.float32, device=dev) if want else None
+    with _timed("motion_grad_lists"):
+        rc = lib.dnmf_motion_grad_lists(layout["At"].data_ptr(), layout["bbox"].data_ptr(), K, C.data_ptr(), C.stride(0),
+                                        frames.data_ptr(), frames.stride(0), _ptr(fid), X, Y, Z, beta.data_ptr(),
+                                        beta.shape[2], tt.data_ptr(), B, int(norm_frames), grad.data_ptr(), _ptr(frame_loss),
+                                        _ptr(reg), chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                        _stream())
+    _lib.check(rc, "dnmf_motion_grad_lists")
+    return {"frame_loss": frame_loss, "reg": reg, "workspace": workspace}
+
+
 def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_stride=0, workspace=None, bf16=False):
     """K3 (``bf16=True``: K3b, operands rounded to bf16, fp32 accumulate).  Returns G (B,K,K), r (B,K) for the
     frames listed."""
@@ -279,9 +308,10 @@ def spatial_accum(Y, C, frame_ids=None, times=None, A1=None, Cs=None, accumulate
         A1 = torch.empty((P, K), dtype=torch.float32, device=dev)
         Cs = torch.empty((K, K), dtype=torch.float32, device=dev)
         accumulate = False
-    _lib.check(_lib.load().dnmf_spatial_accum(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), _ptr(tt),
-                                              T, P, K, A1.data_ptr(), Cs.data_ptr(), int(bool(accumulate)), _stream()),
-               "dnmf_spatial_accum")
+    with _timed("spatial_accum"):
+        rc = _lib.load().dnmf_spatial_accum(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), _ptr(tt),
+                                            T, P, K, A1.data_ptr(), Cs.data_ptr(), int(bool(accumulate)), _stream())
+    _lib.check(rc, "dnmf_spatial_accum")
     return A1, Cs
 
 
@@ -292,8 +322,10 @@ def mu_spatial(A, A1, Cs, D=None, gamma=0.0):
     if D is not None:
         _f32(D, "D")
     P, K = A.shape
-    _lib.check(_lib.load().dnmf_mu_spatial(A.data_ptr(), A1.data_ptr(), Cs.data_ptr(), _ptr(D), float(gamma or 0.0), P, K,
-                                           _stream()), "dnmf_mu_spatial")
+    with _timed("mu_spatial"):
+        rc = _lib.load().dnmf_mu_spatial(A.data_ptr(), A1.data_ptr(), Cs.data_ptr(), _ptr(D), float(gamma or 0.0), P, K,
+                                         _stream())
+    _lib.check(rc, "dnmf_mu_spatial")
     return A
 
 
@@ -413,8 +445,9 @@ class Communicator:
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of a contiguous fp32 CUDA tensor."""
         t = _f32(t, "all_reduce_")
-        _lib.check(_lib.load().dnmf_allreduce_sum_f32(self._handle, _ptr(t), t.numel(), _stream()),
-                   "dnmf_allreduce_sum_f32")
+        with _timed("allreduce"):
+            rc = _lib.load().dnmf_allreduce_sum_f32(self._handle, _ptr(t), t.numel(), _stream())
+        _lib.check(rc, "dnmf_allreduce_sum_f32")
         return t
 
     def close(self):
@@ -446,10 +479,12 @@ def image_iwarp(frames, frame_ids, sz, beta, times, out=None, exhaustive=False, 
     for s in range(0, B, step):
         n = min(step, B - s)
         src = frames if fid is not None else frames[s:]   # without ids, frame b of a launch is its row b
-        _lib.check(lib.dnmf_image_iwarp(src.data_ptr(), frames.stride(0), 0 if fid is None else fid[s:].data_ptr(), X, Y, Z,
+        with _timed("image_iwarp"):
+            rc = (lib.dnmf_image_iwarp(src.data_ptr(), frames.stride(0), 0 if fid is None else fid[s:].data_ptr(), X, Y, Z,
                                         beta.data_ptr(), beta.shape[2], tt[s:].data_ptr(), n, out[s:].data_ptr(),
                                         out.stride(0), ws.data_ptr(), ws.numel(), int(bool(exhaustive)), _ptr(count),
-                                        _stream()), "dnmf_image_iwarp")
+                                        _stream()))
+        _lib.check(rc, "dnmf_image_iwarp")
     return out
 
 

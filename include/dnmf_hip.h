@@ -189,6 +189,18 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
 int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
                            const int *times, int B, float *S, long lds, dnmf_stream_t stream);
 
+/* One group of mini-batches of the fused motion epoch with the reconstruction images kept in the last-level cache:
+ * dnmf_recon_image_lists and dnmf_warp_recon_grad (its frames / frame_ids / times / norm_frames / grad / frame_loss / reg
+ * arguments, no upstream gradient, A_tC not returned) alternate over pieces of `chunk` frames that share ONE buffer of
+ * `chunk` images, so S_t = A.C_t never makes the round trip through HBM (Demix/dNMF.py:58 + 186-190 for B frames).
+ * Same kernels and sums as the two calls on all B frames.  norm_frames > 0 is required;
+ * workspace: dnmf_motion_grad_lists_workspace(X,Y,Z,chunk) bytes. */
+size_t dnmf_motion_grad_lists_workspace(int X, int Y, int Z, int chunk);
+int dnmf_motion_grad_lists(const float *At, const int *bbox, int K, const float *C, long ldc, const float *frames, long ldf,
+                           const int *frame_ids, int X, int Y, int Z, const float *beta, int T, const int *times, int B,
+                           int norm_frames, float *grad, float *frame_loss, float *reg, int chunk, void *workspace,
+                           size_t workspace_bytes, dnmf_stream_t stream);
+
 /* ---- K4: multiplicative update of the traces --------------------------------------------------------
  * C <- C * (r + gamma*nbr) / (G C + 2 gamma C + 1e-32)  (Demix/dNMF.py:143-148, looped at dNMF.py:172-173)
  * on the hoisted G, r.  Arithmetic in fp64 like the reference's numpy code.
