@@ -295,9 +295,11 @@ class DeformableNMF:
         self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
         self._spatial_buf = None   # A1 (P,K) and C_s (K,K) of spatial_step, one buffer = one all-reduce
         self._ws_mg = None
-        # frames per piece of the fused motion epoch on compact footprints: a piece's reconstruction images (1.1 MB each
-        # at 512x512) and its frames must fit the 256 MB Infinity Cache together; 0 = all frames at once through HBM
-        self.motion_chunk = 64
+        # > 0: the fused motion epoch on compact footprints makes its reconstruction images this many frames at a time
+        # into one small buffer (dnmf_motion_grad_lists) instead of keeping the images of all T frames (4.5 GB at
+        # 512x512x4000): same results bit for bit, same speed within 2 % from 128 frames on (the hoped-for gain from
+        # images that stay in the Infinity Cache did not materialise), so it is a memory option; 0 = all frames at once
+        self.motion_chunk = 0
         self._stage_buf = None     # device copy of the frames a host loader served in its last pass
         self._reg_buf = None       # registered frames (K7) of the last update_footprints(live_spatial=True)
         self._D_dev = None         # (id(self.D), fp32 device copy of D flattened to (P,K))
@@ -308,17 +310,20 @@ class DeformableNMF:
     @staticmethod
     def update_temporal(A_t, C, Y, gamma=None):
         """One multiplicative update of ``C`` given explicit warped footprints (reference :139-149).
-        ``A_t`` (X,Y,Z,K,T), ``C`` (K,T), ``Y`` (X,Y,Z,T) numpy; returns float64 numpy (K,T)."""
+        ``A_t`` (X,Y,Z,K,T), ``C`` (K,T), ``Y`` (X,Y,Z,T) numpy; returns float64 numpy (K,T).  The contraction runs on
+        the fp32 matrix cores (K3 without a warp: every voxel's own row of ``A_t``), the update in float64 (K4); at
+        most 127 neurons per call (one K3 launch)."""
         A_t, C, Y = np.asarray(A_t), np.asarray(C), np.asarray(Y)
         X, Y_, Z, K, T = A_t.shape
+        if K > 127:
+            raise ValueError(f"update_temporal (static): K={K} > 127 neurons; use DeformableNMF.update_footprints, which "
+                             "cuts the neurons into groups")
         P = X * Y_ * Z
         dev = torch.device(device)
         A_dev = torch.from_numpy(np.ascontiguousarray(np.moveaxis(A_t, 4, 0).reshape(T, P, K))).to(dev, torch.float32)
         Apk = ops.pack_footprints(A_dev)                                   # (T*P, Kp)
         frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(Y, 3, 0).reshape(T, P))).to(dev, torch.float32)
-        ident = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].repeat(1, 1, T).to(dev)
-        G, r, _ = ops.warp_gram_rhs(Apk, K, (X, Y_, Z), ident.contiguous(), list(range(T)), frames,
-                                    a_frame_stride=P * Apk.shape[1])
+        G, r, _ = ops.warp_gram_rhs(Apk, K, (X, Y_, Z), None, list(range(T)), frames, a_frame_stride=P * Apk.shape[1])
         return _mu_temporal(G, r, torch.from_numpy(np.asarray(C, dtype=np.float64)).to(dev), gamma, 1).cpu().numpy()
 
     @staticmethod

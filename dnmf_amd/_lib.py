@@ -58,7 +58,7 @@ SIGNATURES = {
     "dnmf_warp_gram_rhs_lists": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp,
                                       _vp, _sz, _vp, _vp]),
     "dnmf_recon_image_lists": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
-    "dnmf_motion_grad_lists_workspace": (_sz, [_i, _i, _i, _i]),
+    "dnmf_motion_grad_lists_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dnmf_motion_grad_lists": (_i, [_vp, _vp, _i, _vp, _l, _vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i,
                                     _vp, _sz, _vp]),
     "dnmf_comm_unique_id": (_i, [_vp]),

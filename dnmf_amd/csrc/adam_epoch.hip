@@ -8,19 +8,23 @@
 // Columns are independent, so the epoch is: phase 0 (coast j steps) -> K2 for all frames -> phase 1 (the
 // gradient step and the remaining coasting).  Arithmetic follows torch's Adam (non-amsgrad, no weight
 // decay): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*exp_avg_sq + (1-b2) g^2; bias corrections 1 - b^step in double,
-// applied as fp32 scalars; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * (m/denom).
+// applied as fp32 scalars; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * (m/denom) -- with the fused multiply-adds
+// torch's GPU kernels contract these expressions into (tools/adam_probe.py compares one optimiser step of the
+// installed torch with the candidate sequences on 10^6 random elements: this one matches on every element).
 #include "common.hpp"
 
 namespace dnmf {
+
+constexpr int ADAM_LITERAL = 64;   // coasting runs up to this length are stepped one by one in torch's own arithmetic
 
 // The step with a gradient, literally torch's: step_size = -(lr / (1 - b1^step)) and bc2_sqrt = sqrt(1 - b2^step) are
 // evaluated in double and rounded to fp32 as torch does.
 __device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, float step_size, float bc2_sqrt,
                                          float b2f, float omb1, float omb2, float epsf) {
-    m = m + omb1 * (g - m);                    // lerp_(grad, 1 - beta1)
-    v = b2f * v + omb2 * (g * g);              // mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    m = fmaf(omb1, g - m, m);                  // lerp_(grad, 1 - beta1)
+    v = fmaf(omb2, g * g, b2f * v);            // mul_(beta2).addcmul_(grad, grad, value=1-beta2)
     const float denom = sqrtf(v) / bc2_sqrt + epsf;
-    p = p + step_size * (m / denom);           // addcdiv_(exp_avg, denom, value=-step_size)
+    p = fmaf(step_size, m / denom, p);         // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 // The step-dependent scalars of steps step0+1 .. step0+nsteps, the same for every column, as one float4 per step:
@@ -39,7 +43,9 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float4 *__restrict__ ta
 //   phase 0: the j_t zero-gradient ("coasting") steps step0+1 .. step0+j_t before the frame's own mini-batch;
 //   phase 1: step step0+j_t+1 with grad, then coasting up to step0+nsteps (frame_step[t] < 0: the frame is in no
 //            mini-batch of this epoch and coasts through all nsteps here).
-// The step with a gradient follows torch's fp32 arithmetic literally.  A run of coasting steps from state (p, m, v)
+// The step with a gradient follows torch's fp32 arithmetic literally, and so does a run of at most ADAM_LITERAL coasting
+// steps (a zero gradient through the same expressions): an epoch of few mini-batches -- the reference's demo has 25 --
+// is then the optimiser's own sequence bit for bit.  A longer run of coasting steps from state (p, m, v)
 // has the closed form m_i = m b1^i, v_i = v b2^i, p += sum_i step_size_i m_i / (sqrt(v_i) / bc2_sqrt_i + eps): the
 // terms are independent, so they are evaluated without the serial dependence of the step-by-step form (powers as
 // running products in double, hardware sqrt / reciprocal, the sum in double) and the loop covers only the steps before
@@ -75,7 +81,12 @@ __global__ __launch_bounds__(256) void adam_epoch_kernel(float *__restrict__ bet
         ++s;
     }
     const int k = last - s + 1;  // coasting steps
-    if (k > 0) {
+    if (k > 0 && k <= ADAM_LITERAL) {
+        for (int r = 0; r < k; ++r) {
+            const float4 q = tab[s - 1 + r];
+            adam_one(p, m, v, 0.0f, q.x, q.y, b2f, omb1, omb2, epsf);
+        }
+    } else if (k > 0) {
         // steps until m b1^i is below the smallest fp32 denormal (2^-149): every later term is exactly zero
         int live_steps = 0;
         if (m != 0.0f) {

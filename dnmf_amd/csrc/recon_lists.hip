@@ -146,51 +146,3 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
 }
 
 }  // extern "C"
-
-// ---- motion gradient with the reconstruction images kept in the last-level cache ---------------------------------
-// The fused epoch of update_motion needs, for every frame, S_t = A.C_t (written by dnmf_recon_image_lists) and then
-// K2's gather from it.  Done for all T frames at once, S makes a round trip through HBM (4.5 GB written and read back
-// at 512x512x4000).  Done `chunk` frames at a time into ONE buffer of `chunk` images, the images are still in the
-// 256 MB Infinity Cache when K2 gathers from them, and the next chunk overwrites them there before they are ever
-// written back: HBM then sees little more than the video itself.  Only the order of the launches changes; every
-// kernel and every sum is the one of the two separate calls.
-extern "C" {
-
-size_t dnmf_motion_grad_lists_workspace(int X, int Y, int Z, int chunk) {
-    if (X <= 0 || Y <= 0 || Z <= 0 || chunk <= 0) return 0;
-    const size_t img = ((size_t)dnmf_halo_voxels(X, Y, Z) * chunk * sizeof(float) + 255) / 256 * 256;
-    return img + dnmf_warp_recon_grad_workspace(X, Y, Z, chunk);
-}
-
-int dnmf_motion_grad_lists(const float *At, const int *bbox, int K, const float *C, long ldc, const float *frames, long ldf,
-                           const int *frame_ids, int X, int Y, int Z, const float *beta, int T, const int *times, int B,
-                           int norm_frames, float *grad, float *frame_loss, float *reg, int chunk, void *workspace,
-                           size_t workspace_bytes, dnmf_stream_t stream) {
-    using namespace dnmf;
-    DNMF_REQUIRE(At && bbox && C && frames && beta && times && grad && workspace, DNMF_E_NULL,
-                 "dnmf_motion_grad_lists: NULL buffer");
-    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && norm_frames > 0 && chunk > 0 && chunk <= 65535,
-                 DNMF_E_SHAPE, "dnmf_motion_grad_lists: X=%d Y=%d Z=%d K=%d T=%d B=%d norm_frames=%d chunk=%d", X, Y, Z, K, T, B,
-                 norm_frames, chunk);
-    DNMF_REQUIRE(workspace_bytes >= dnmf_motion_grad_lists_workspace(X, Y, Z, chunk), DNMF_E_WORKSPACE,
-                 "dnmf_motion_grad_lists: workspace %zu < %zu bytes", workspace_bytes,
-                 dnmf_motion_grad_lists_workspace(X, Y, Z, chunk));
-    const long lds = dnmf_halo_voxels(X, Y, Z);
-    const size_t img = ((size_t)lds * chunk * sizeof(float) + 255) / 256 * 256;
-    float *S = static_cast<float *>(workspace);
-    void *ws2 = static_cast<char *>(workspace) + img;
-    const size_t ws2_bytes = workspace_bytes - img;
-    for (int c0 = 0; c0 < B; c0 += chunk) {
-        const int n = B - c0 < chunk ? B - c0 : chunk;
-        int rc = dnmf_recon_image_lists(At, bbox, K, X, Y, Z, C, ldc, times + c0, n, S, lds, stream);
-        if (rc != 0) return rc;
-        rc = dnmf_warp_recon_grad(S, lds, nullptr, frame_ids ? frames : frames + (long)c0 * ldf, ldf,
-                                  frame_ids ? frame_ids + c0 : nullptr, nullptr, X, Y, Z, beta, T, times + c0, n, norm_frames,
-                                  nullptr, grad, nullptr, frame_loss ? frame_loss + c0 : nullptr, reg ? reg + c0 : nullptr, ws2,
-                                  ws2_bytes, stream);
-        if (rc != 0) return rc;
-    }
-    return DNMF_OK;
-}
-
-}  // extern "C"

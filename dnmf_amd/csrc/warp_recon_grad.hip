@@ -348,34 +348,12 @@ int dnmf_halo_row(int Y, int Z) {
     return dnmf::make_halo_layout(1, Y, Z).rowf;
 }
 
-int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
-                         const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta, int T,
-                         const int *times, int B, int norm_frames, float *recon, float *grad, float *loss, float *frame_loss, float *reg,
-                         void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+// the main kernel of K2 for B frames: per-block partial sums into `partial` (B, nblk, K2_NACC)
+static void k2_launch_main(const float *S, long lds, const int *s_ids, const float *frames, long ldf, const int *frame_ids,
+                           const float *gout, const dnmf::Volume &vol, const dnmf::HaloLayout &hl, const float *beta, int T,
+                           const int *times, int B, float *recon, float *partial, const float2 *xtab, int nblk, int nub,
+                           hipStream_t st) {
     using namespace dnmf;
-    DNMF_REQUIRE(S && (frames || gout) && beta && times && workspace, DNMF_E_NULL,
-                 "dnmf_warp_recon_grad: NULL input");
-    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && T > 0 && B > 0 && B <= 65535, DNMF_E_SHAPE,
-                 "dnmf_warp_recon_grad: X=%d Y=%d Z=%d T=%d B=%d", X, Y, Z, T, B);
-    const Volume vol = make_volume(X, Y, Z);
-    const HaloLayout hl = make_halo_layout(X, Y, Z);
-    DNMF_REQUIRE(lds >= hl.Pp && (!frames || ldf >= vol.P), DNMF_E_SHAPE,
-                 "dnmf_warp_recon_grad: lds=%ld < %ld (halo layout) or ldf=%ld < P=%ld", lds, hl.Pp, ldf, vol.P);
-    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(X, Y, Z, B), DNMF_E_WORKSPACE,
-                 "dnmf_warp_recon_grad: workspace %zu < %zu bytes", workspace_bytes,
-                 dnmf_warp_recon_grad_workspace(X, Y, Z, B));
-    // 32-bit byte offsets into an image; 24-bit multiplies for the tap offsets
-    DNMF_REQUIRE(hl.Pp < (1L << 29) && hl.row4 < (1 << 23) && hl.Xp < (1 << 23), DNMF_E_UNSUPPORTED,
-                 "dnmf_warp_recon_grad: volume %dx%dx%d too large for 32-bit tap offsets", X, Y, Z);
-    int nub = 0;
-    const long nblk_l = k2_blocks(X, Y, Z, &nub);
-    DNMF_REQUIRE(nblk_l < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_warp_recon_grad: %ld blocks per frame", nblk_l);
-    const int nblk = (int)nblk_l;
-    float2 *xtab = static_cast<float2 *>(workspace);
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + k2_xtab_bytes(X));
-    float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k2_xtab_kernel, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, st, xtab, X);
     const dim3 grid((unsigned)nblk, (unsigned)B);
 #define DNMF_K2_LAUNCH(HZ, FD, FO, PL)                                                                                     \
     hipLaunchKernelGGL((warp_recon_grad_kernel<HZ, FD, FO, PL>), grid, dim3(256), 0, st, S, lds, s_ids, frames, ldf,      \
@@ -385,19 +363,117 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
     else if (vol.fastdiv) DNMF_K2_LAUNCH(HZ, 1, false, PL);         \
     else DNMF_K2_LAUNCH(HZ, 0, false, PL)
     const bool plain = frames && !gout && !recon;
-    if (Z > 1) {
+    if (vol.Z > 1) {
         if (plain) { DNMF_K2_VARIANTS(true, true); } else { DNMF_K2_VARIANTS(true, false); }
     } else {
         if (plain) { DNMF_K2_VARIANTS(false, true); } else { DNMF_K2_VARIANTS(false, false); }
     }
 #undef DNMF_K2_VARIANTS
 #undef DNMF_K2_LAUNCH
+}
+
+// argument checks shared by the two entry points; fills vol / hl / nblk / nub
+static int k2_geometry(const char *who, int X, int Y, int Z, dnmf::Volume &vol, dnmf::HaloLayout &hl, int &nblk, int &nub) {
+    using namespace dnmf;
+    vol = make_volume(X, Y, Z);
+    hl = make_halo_layout(X, Y, Z);
+    // 32-bit byte offsets into an image; 24-bit multiplies for the tap offsets
+    DNMF_REQUIRE(hl.Pp < (1L << 29) && hl.row4 < (1 << 23) && hl.Xp < (1 << 23), DNMF_E_UNSUPPORTED,
+                 "%s: volume %dx%dx%d too large for 32-bit tap offsets", who, X, Y, Z);
+    const long nblk_l = k2_blocks(X, Y, Z, &nub);
+    DNMF_REQUIRE(nblk_l < (1L << 31), DNMF_E_UNSUPPORTED, "%s: %ld blocks per frame", who, nblk_l);
+    nblk = (int)nblk_l;
+    return DNMF_OK;
+}
+
+int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float *frames, long ldf,
+                         const int *frame_ids, const float *gout, int X, int Y, int Z, const float *beta, int T,
+                         const int *times, int B, int norm_frames, float *recon, float *grad, float *loss, float *frame_loss, float *reg,
+                         void *workspace, size_t workspace_bytes, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(S && (frames || gout) && beta && times && workspace, DNMF_E_NULL,
+                 "dnmf_warp_recon_grad: NULL input");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && T > 0 && B > 0 && B <= 65535, DNMF_E_SHAPE,
+                 "dnmf_warp_recon_grad: X=%d Y=%d Z=%d T=%d B=%d", X, Y, Z, T, B);
+    Volume vol;
+    HaloLayout hl;
+    int nblk = 0, nub = 0;
+    const int rc = k2_geometry("dnmf_warp_recon_grad", X, Y, Z, vol, hl, nblk, nub);
+    if (rc != 0) return rc;
+    DNMF_REQUIRE(lds >= hl.Pp && (!frames || ldf >= vol.P), DNMF_E_SHAPE,
+                 "dnmf_warp_recon_grad: lds=%ld < %ld (halo layout) or ldf=%ld < P=%ld", lds, hl.Pp, ldf, vol.P);
+    DNMF_REQUIRE(workspace_bytes >= dnmf_warp_recon_grad_workspace(X, Y, Z, B), DNMF_E_WORKSPACE,
+                 "dnmf_warp_recon_grad: workspace %zu < %zu bytes", workspace_bytes,
+                 dnmf_warp_recon_grad_workspace(X, Y, Z, B));
+    float2 *xtab = static_cast<float2 *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + k2_xtab_bytes(X));
+    float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k2_xtab_kernel, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, st, xtab, X);
+    k2_launch_main(S, lds, s_ids, frames, ldf, frame_ids, gout, vol, hl, beta, T, times, B, recon, partial, xtab, nblk, nub, st);
     if (norm_frames <= 0) norm_frames = B;
     const float grad_scale = gout ? 1.0f : 2.0f / ((float)norm_frames * (float)vol.P);
     hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T,
                        times, norm_frames, grad_scale, grad, (loss || frame_loss) ? fl : nullptr, reg);
     if (loss) hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(64), 0, st, fl, B, loss);
     return check_launch("dnmf_warp_recon_grad");
+}
+
+// ---- motion gradient with the reconstruction images kept in the last-level cache ---------------------------------
+// The fused epoch of update_motion needs, for every frame, S_t = A.C_t (written by dnmf_recon_image_lists) and then
+// K2's gather from it.  Done for all T frames at once, S makes a round trip through HBM (4.5 GB written and read back
+// at 512x512x4000).  Done `chunk` frames at a time into ONE buffer of `chunk` images, the images are still in the
+// 256 MB Infinity Cache when K2 gathers from them, and the next piece overwrites them there before they are ever
+// written back.  Only the order of the launches changes: the reconstruction kernel and K2's main kernel alternate, K2's
+// finish kernel runs once over all frames at the end; every kernel and every sum is the one of the two separate calls.
+static size_t motion_images_bytes(int X, int Y, int Z, int chunk) {
+    return ((size_t)dnmf_halo_voxels(X, Y, Z) * chunk * sizeof(float) + 255) / 256 * 256;
+}
+
+size_t dnmf_motion_grad_lists_workspace(int X, int Y, int Z, int chunk, int B) {
+    if (X <= 0 || Y <= 0 || Z <= 0 || chunk <= 0 || B <= 0) return 0;
+    return motion_images_bytes(X, Y, Z, chunk) + k2_xtab_bytes(X) +
+           (size_t)B * k2_blocks(X, Y, Z, nullptr) * dnmf::K2_NACC * sizeof(float) + (size_t)B * sizeof(float);
+}
+
+int dnmf_motion_grad_lists(const float *At, const int *bbox, int K, const float *C, long ldc, const float *frames, long ldf,
+                           const int *frame_ids, int X, int Y, int Z, const float *beta, int T, const int *times, int B,
+                           int norm_frames, float *grad, float *frame_loss, float *reg, int chunk, void *workspace,
+                           size_t workspace_bytes, dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(At && bbox && C && frames && beta && times && grad && workspace, DNMF_E_NULL,
+                 "dnmf_motion_grad_lists: NULL buffer");
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && T > 0 && B > 0 && norm_frames > 0 && chunk > 0 && chunk <= 65535,
+                 DNMF_E_SHAPE, "dnmf_motion_grad_lists: X=%d Y=%d Z=%d K=%d T=%d B=%d norm_frames=%d chunk=%d", X, Y, Z, K, T, B,
+                 norm_frames, chunk);
+    Volume vol;
+    HaloLayout hl;
+    int nblk = 0, nub = 0;
+    int rc = k2_geometry("dnmf_motion_grad_lists", X, Y, Z, vol, hl, nblk, nub);
+    if (rc != 0) return rc;
+    DNMF_REQUIRE(ldf >= vol.P, DNMF_E_SHAPE, "dnmf_motion_grad_lists: ldf=%ld < P=%ld", ldf, vol.P);
+    DNMF_REQUIRE(workspace_bytes >= dnmf_motion_grad_lists_workspace(X, Y, Z, chunk, B), DNMF_E_WORKSPACE,
+                 "dnmf_motion_grad_lists: workspace %zu < %zu bytes", workspace_bytes,
+                 dnmf_motion_grad_lists_workspace(X, Y, Z, chunk, B));
+    float *S = static_cast<float *>(workspace);
+    char *at = static_cast<char *>(workspace) + motion_images_bytes(X, Y, Z, chunk);
+    float2 *xtab = reinterpret_cast<float2 *>(at);
+    float *partial = reinterpret_cast<float *>(at + k2_xtab_bytes(X));
+    float *fl = frame_loss ? frame_loss : partial + (size_t)B * nblk * K2_NACC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k2_xtab_kernel, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, st, xtab, X);
+    for (int c0 = 0; c0 < B; c0 += chunk) {
+        const int n = B - c0 < chunk ? B - c0 : chunk;
+        rc = dnmf_recon_image_lists(At, bbox, K, X, Y, Z, C, ldc, times + c0, n, S, hl.Pp, stream);
+        if (rc != 0) return rc;
+        k2_launch_main(S, hl.Pp, nullptr, frame_ids ? frames : frames + (long)c0 * ldf, ldf, frame_ids ? frame_ids + c0 : nullptr,
+                       nullptr, vol, hl, beta, T, times + c0, n, nullptr, partial + (size_t)c0 * nblk * K2_NACC, xtab, nblk, nub,
+                       st);
+    }
+    const float grad_scale = 2.0f / ((float)norm_frames * (float)vol.P);
+    hipLaunchKernelGGL(warp_recon_grad_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, partial, nblk, vol, beta, T, times,
+                       norm_frames, grad_scale, grad, frame_loss ? fl : nullptr, reg);
+    return check_launch("dnmf_motion_grad_lists");
 }
 
 }  // extern "C"

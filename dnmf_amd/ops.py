@@ -184,7 +184,7 @@ def motion_grad_lists(layout, K, sz, C, frames, frame_ids, beta, times, grad, no
     B = tt.numel()
     lib = _lib.load()
     chunk = max(1, min(int(chunk), B))
-    need = lib.dnmf_motion_grad_lists_workspace(X, Y, Z, chunk)
+    need = lib.dnmf_motion_grad_lists_workspace(X, Y, Z, chunk, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
     frame_loss = torch.empty((B,), dtype=torch.float32, device=dev) if want else None
@@ -201,11 +201,13 @@ def motion_grad_lists(layout, K, sz, C, frames, frame_ids, beta, times, grad, no
 
 def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_stride=0, workspace=None, bf16=False):
     """K3 (``bf16=True``: K3b, operands rounded to bf16, fp32 accumulate).  Returns G (B,K,K), r (B,K) for the
-    frames listed."""
+    frames listed.  ``beta`` None: no warp (each voxel's own footprint row, weight 1)."""
     X, Y, Z = (int(s) for s in sz)
     P = X * Y * Z
     dev = Apk.device
-    _f32(Apk, "Apk"), _f32(beta, "beta")
+    _f32(Apk, "Apk")
+    if beta is not None:
+        _f32(beta, "beta")
     lib = _lib.load()
     tt = _i32(times, dev) if times is not None else None
     fid = _i32(frame_ids, dev) if frame_ids is not None else None
@@ -219,8 +221,8 @@ def warp_gram_rhs(Apk, K, sz, beta, times, frames, frame_ids=None, a_frame_strid
     r = torch.empty((B, K), dtype=torch.float32, device=dev)
     with _timed("warp_gram_rhs_bf16" if bf16 else "warp_gram_rhs"):
         rc = (lib.dnmf_warp_gram_rhs_bf16 if bf16 else lib.dnmf_warp_gram_rhs)(
-            Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, beta.data_ptr(), beta.shape[2], _ptr(tt), B,
-            frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
+            Apk.data_ptr(), Apk.shape[-1], K, a_frame_stride, X, Y, Z, _ptr(beta), B if beta is None else beta.shape[2],
+            _ptr(tt), B, frames.data_ptr(), frames.stride(0), _ptr(fid), G.data_ptr(), r.data_ptr(), workspace.data_ptr(),
             workspace.numel() * workspace.element_size(), _stream())
     _lib.check(rc, "dnmf_warp_gram_rhs")
     return G, r, workspace

@@ -112,6 +112,8 @@ int dnmf_warp_recon_grad(const float *S, long lds, const int *s_ids, const float
  * fp32 MFMA (v_mfma_f32_16x16x4_f32), upper triangle only, symmetric fill.
  *   Apk      packed footprints; a_frame_stride 0 = one A for all frames, else floats between the
  *            per-frame packed A of consecutive b (static update_temporal on an explicit A_t)
+ *   beta     NULL = no warp: every voxel takes its own footprint row with weight 1 (the static update_temporal of
+ *            Demix/dNMF.py:139-149 on an explicit A_t; a trilinear re-sampling at the identity is not exact in fp32)
  *   times    (B) or NULL (-> 0..B-1); frames / ldf / frame_ids as in K2
  *   G (B,K,K), r (B,K); workspace: dnmf_warp_gram_rhs_workspace(P,K,B) bytes */
 size_t dnmf_warp_gram_rhs_workspace(long P, int K, int B);
@@ -193,9 +195,9 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
  * dnmf_recon_image_lists and dnmf_warp_recon_grad (its frames / frame_ids / times / norm_frames / grad / frame_loss / reg
  * arguments, no upstream gradient, A_tC not returned) alternate over pieces of `chunk` frames that share ONE buffer of
  * `chunk` images, so S_t = A.C_t never makes the round trip through HBM (Demix/dNMF.py:58 + 186-190 for B frames).
- * Same kernels and sums as the two calls on all B frames.  norm_frames > 0 is required;
- * workspace: dnmf_motion_grad_lists_workspace(X,Y,Z,chunk) bytes. */
-size_t dnmf_motion_grad_lists_workspace(int X, int Y, int Z, int chunk);
+ * Same kernels and sums as the two calls on all B frames (K2's finish kernel runs once at the end).  norm_frames > 0 is
+ * required; B may exceed 65535; workspace: dnmf_motion_grad_lists_workspace(X,Y,Z,chunk,B) bytes. */
+size_t dnmf_motion_grad_lists_workspace(int X, int Y, int Z, int chunk, int B);
 int dnmf_motion_grad_lists(const float *At, const int *bbox, int K, const float *C, long ldc, const float *frames, long ldf,
                            const int *frame_ids, int X, int Y, int Z, const float *beta, int T, const int *times, int B,
                            int norm_frames, float *grad, float *frame_loss, float *reg, int chunk, void *workspace,

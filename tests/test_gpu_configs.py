@@ -476,3 +476,120 @@ def test_stock_dataloader_is_staged_and_matches_the_resident_path(M, O, monkeypa
     d.update_motion(loader(6), opt_d, gamma=1, epochs=2)
     assert torch.equal(c.fp.beta, d.fp.beta)
     assert not torch.equal(c.fp.beta, a.fp.beta)
+
+
+@pytest.mark.parametrize("sz", [[1, 40, 3], [9, 1, 1], [600, 3, 1]])
+def test_static_update_temporal_takes_A_t_as_it_is(M, O, sz):
+    """The static update_temporal (reference Demix/dNMF.py:139-149) contracts the A_t it is handed without re-sampling
+    it: axes of length one (a trilinear round trip divides 0/0 there) and a long axis (where an fp32 round trip of the
+    lattice is off by a few 1e-6 voxels) must match the oracle like any other shape."""
+    rng = np.random.RandomState(sum(sz))
+    K, T = 7, 3
+    A_t = rng.rand(*sz, K, T)
+    C = 0.3 + rng.rand(K, T)
+    Y = rng.rand(*sz, T)
+    for gamma in (None, 1e-2):
+        got = M.DeformableNMF.update_temporal(A_t, C, Y, gamma=gamma)
+        want = O.update_temporal(A_t, C, Y, gamma=gamma)
+        np.testing.assert_allclose(got, want, rtol=2e-5)
+    with pytest.raises(ValueError):
+        M.DeformableNMF.update_temporal(rng.rand(2, 2, 1, 128, 1), rng.rand(128, 1), rng.rand(2, 2, 1, 1))
+
+
+def test_short_adam_epoch_is_torch_bit_for_bit(M):
+    """An epoch of at most 64 mini-batches: dnmf_adam_epoch steps every column through torch's own fp32 sequence (the
+    fused multiply-adds of its GPU kernels, tools/adam_probe.py), so beta and both moments must EQUAL those of
+    torch.optim.Adam stepped once per mini-batch with the gradients injected at their steps -- two epochs, frames without
+    a mini-batch, first and last step."""
+    from dnmf_amd import ops
+    torch.manual_seed(4)
+    T, nsteps, lr = 40, 25, 1e-3
+    beta = (torch.randn(10, 3, T, device="cuda") * 0.1 + 1.0).contiguous()
+    ref = beta.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=lr)
+    m, v = torch.zeros_like(beta), torch.zeros_like(beta)
+    for epoch in range(2):
+        gen = torch.Generator().manual_seed(epoch)
+        fs = torch.randint(0, nsteps, (T,), generator=gen, dtype=torch.int32)
+        fs[::7] = -1
+        fs[1], fs[2] = 0, nsteps - 1
+        ops.adam_epoch(beta, None, m, v, epoch * nsteps, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=0)
+        grad = torch.randn(10, 3, T, device="cuda") * 1e-2
+        grad[:, :, fs.cuda() < 0] = 0
+        ops.adam_epoch(beta, grad, m, v, epoch * nsteps, fs, nsteps, lr, (0.9, 0.999), 1e-8, phase=1)
+        for s in range(nsteps):
+            g = torch.zeros_like(beta)
+            sel = (fs == s).cuda()
+            g[:, :, sel] = grad[:, :, sel]
+            ref.grad = g
+            opt.step()
+        st = opt.state[ref]
+        assert torch.equal(beta, ref.detach()), float((beta - ref.detach()).abs().max())
+        assert torch.equal(m, st["exp_avg"]) and torch.equal(v, st["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("sz", [[20, 16, 2], [40, 36, 1]])
+def test_fused_motion_epochs_equal_the_stepwise_run_bit_for_bit(M, O, sz):
+    """update_motion through the fused epoch (per-column Adam kernel, one K2 launch per group of mini-batches) and
+    through one K2 launch + one optimizer.step() of torch per mini-batch: the same beta, bit for bit, after three
+    shuffled epochs from the identity -- the start at which one ulp of beta decides which lattice cell a voxel falls
+    into (the first Adam step moves every coefficient by exactly lr), so "close" would not be good enough."""
+    rng = np.random.RandomState(1)
+    K, T, bs = 4, 10, 4
+    pos = rng.rand(K, 3) * np.array(sz)
+    video = torch.from_numpy(rng.rand(T, *sz).astype(np.float32))
+    orders = [rng.permutation(T).tolist() for _ in range(3)]
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+        dn.verbose, dn.fused_motion = False, fused
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+        for perm in orders:
+            batches = [perm[s0:s0 + bs] for s0 in range(0, T, bs)]
+            dn.update_motion([(video[b], torch.tensor(b)) for b in batches], opt, gamma=1, epochs=1)
+        out.append((dn.fp.beta.detach().clone(), opt.state[dn.fp.beta]["exp_avg"].clone(),
+                    opt.state[dn.fp.beta]["exp_avg_sq"].clone(), float(opt.state[dn.fp.beta]["step"])))
+    assert out[0][3] == out[1][3] == 9.0
+    assert torch.equal(out[0][0], out[1][0]), float((out[0][0] - out[1][0]).abs().max())
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert float((out[0][0] - torch.from_numpy(O.identity_beta(T)).cuda()).abs().max()) > 1e-3
+
+
+def test_motion_grad_in_pieces_is_the_same_gradient(M):
+    """dnmf_motion_grad_lists (reconstruction images made `chunk` frames at a time into one small buffer) against
+    dnmf_recon_image_lists + dnmf_warp_recon_grad on all frames: identical gradient, losses and reg, also with row ids,
+    a piece size that does not divide the number of frames and through the model (motion_chunk)."""
+    from dnmf_amd import ops
+    torch.manual_seed(2)
+    sz, K, T = [70, 52, 1], 9, 23
+    pos = torch.rand(K, 3) * torch.tensor([70.0, 52.0, 0.0])
+    fp = M.ExponentialFP(torch.tensor(sz), K, T, positions=pos)
+    with torch.no_grad():
+        fp.beta += 1e-2 * torch.randn_like(fp.beta) * torch.tensor([50, 1, 1, 0, 1e-2, 1e-2, 0, 1e-2, 0, 0], device="cuda")[:, None, None]
+        fp.beta[:, 2] = torch.tensor([0., 0, 0, 1, 0, 0, 0, 0, 0, 0], device="cuda")[:, None]
+    C = torch.rand(K, T, device="cuda")
+    frames = torch.rand(T + 5, fp.P, device="cuda")
+    rows = torch.randperm(T + 5)[:T].to(torch.int32).cuda()
+    times = torch.randperm(T).to(torch.int32).cuda()
+    ly = fp.packed_lists()
+    beta = fp.beta.detach()
+    S = ops.recon_image_lists(ly, K, sz, C, times)
+    g0 = torch.zeros_like(beta)
+    ref = ops.warp_recon_grad(S, None, frames, rows, sz, beta, times, grad=g0, norm_frames=4)
+    for chunk in (1, 5, 8, 23, 64):
+        g = torch.zeros_like(beta)
+        out = ops.motion_grad_lists(ly, K, sz, C, frames, rows, beta, times, g, 4, chunk, want=True)
+        assert torch.equal(g, g0), chunk
+        assert torch.equal(out["frame_loss"], ref["frame_loss"]) and torch.equal(out["reg"], ref["reg"])
+    a = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    b = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    res = []
+    for dn, chunk in ((a, 0), (b, 6)):
+        dn.verbose, dn.motion_chunk = False, chunk
+        dn.C = C.clone()
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-3)
+        dn.update_motion(M.ResidentLoader(frames[:T], sz, 4, shuffle=True, generator=torch.Generator().manual_seed(1)), opt,
+                         gamma=1, epochs=2)
+        res.append(dn.fp.beta.detach().clone())
+    assert torch.equal(res[0], res[1])

@@ -26,7 +26,7 @@
 // pass), parked in wave-private LDS and re-read as broadcasts by the 16 lanes that share the voxel.
 // The fp32 sequence for the coordinates is common.hpp's (bit-compatible with the reference's
 // normalise / grid_sample un-normalise round trip).
-#include "common.hpp"
+#include "../dnmf_amd/csrc/common.hpp"
 
 namespace dnmf {
 
@@ -221,18 +221,25 @@ __global__ __launch_bounds__(256, NTAP == 4 ? 2 : 1) void warp_gram_kernel(GramP
         for (int q = 0; q < NQ; ++q) {
             st.w[q] = rc.w[q];
 #pragma unroll
+#if ABL == 2
+            load_row<NB>(st.raw[4 * q], Ab, rc.rr[q][0] + lane_a, rc.rr[q][0] + lane_b);
+            for (int e = 1; e < 4; ++e) st.raw[4 * q + e] = st.raw[4 * q];
+#else
             for (int e = 0; e < 4; ++e) load_row<NB>(st.raw[4 * q + e], Ab, rc.rr[q][e] + lane_a, rc.rr[q][e] + lane_b);
+#endif
         }
         st.y = rc.y;
     };
     auto blend = [&](const Stage &st, float (&frag)[NB]) {
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) frag[bb] = st.raw[0].v[bb] * st.w[0][0];
+#if ABL != 1
 #pragma unroll
         for (int c = 1; c < NTAP; ++c) {
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) frag[bb] = fmaf(st.raw[c].v[bb], st.w[c >> 2][c & 3], frag[bb]);
         }
+#endif
         frag[NB - 1] = ylane ? st.y : frag[NB - 1];
     };
     auto mfmas = [&](const float (&frag)[NB]) {
