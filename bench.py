@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--frames", type=int, default=4000, help="frames per GPU")
     ap.add_argument("--neurons", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--lr", type=float, default=None,
+                    help="Adam learning rate on beta; default 1e-5 * (50 / size)^2: the demo's 1e-5 (demo.py:42) moves the "
+                         "far corner of its 50 x 50 volume by 0.025 px per step through the quadratic coefficients; the same "
+                         "number on a 512 x 512 volume is 2.6 px per step, and the fit (the reference's too) throws whole "
+                         "footprints out of the volume within one epoch, after which traces overflow and beta turns NaN")
     ap.add_argument("--iter-c", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -106,7 +111,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(size, K, batch, iter_c, positions0, frames_host):
+def cpu_baseline(size, K, batch, iter_c, positions0, frames_host, lr):
     """The oracle's faithful restatement of the reference sweep on a bounded sample of the same workload."""
     from oracle import dnmf_oracle as O
     sz = [size, size, 1]
@@ -115,7 +120,7 @@ def cpu_baseline(size, K, batch, iter_c, positions0, frames_host):
     torch.manual_seed(0)
     m = O.OracleModel(sz, K, nb, positions0, C0=torch.rand(K, nb).numpy())
     video = np.ascontiguousarray(np.moveaxis(frames_host[:nb].reshape(nb, size, size, 1), 0, 3))
-    opt = torch.optim.Adam([m.beta_param], lr=1e-5)
+    opt = torch.optim.Adam([m.beta_param], lr=lr)
     t0 = time.perf_counter()
     m.update_motion(video, [list(range(nb))], opt, gamma=1, epochs=1)
     t_motion = (time.perf_counter() - t0) / nb
@@ -191,7 +196,8 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     dn.verbose = False
     dn.gram_kernel = args.gram
     dn.group = group
-    opt = torch.optim.Adam([dn.fp.beta], lr=1e-5)
+    lr = args.lr if args.lr is not None else 1e-5 * (50.0 / sz[0]) ** 2
+    opt = torch.optim.Adam([dn.fp.beta], lr=lr)
     if loader == "resident":
         # every rank draws the SAME global mini-batch order and keeps its own frames: the optimiser-step sequence
         # is the single-process one for the 4000*N-frame video (dnmf_amd/sharding.py)
@@ -237,19 +243,30 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
         elapsed = float(tt[0])
     lists_counters = None if ops.LISTS_COUNTERS is None else ops.LISTS_COUNTERS.tolist()
     sparse_counters = None if ops.SPARSE_COUNTERS is None else ops.SPARSE_COUNTERS.tolist()
+    # the sweeps must have worked on a sane fit: a frame whose beta is not finite gathers nothing and costs K3n nothing
+    beta = dn.fp.beta.detach()
+    ident = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].to(beta.device)
+    sanity = {"finite_beta_frames": int(torch.isfinite(beta).all(0).all(0).sum()), "frames": T_loc,
+              "finite_trace_entries": int(torch.isfinite(dn.C).sum()), "trace_entries": dn.C.numel(),
+              "max_abs_beta_minus_identity": float((beta - ident).abs().nan_to_num(float("inf")).max()),
+              "max_trace": float(dn.C.nan_to_num(float("inf")).max()), "lr": lr}
+    sanity["ok"] = sanity["finite_beta_frames"] == T_loc and sanity["finite_trace_entries"] == dn.C.numel()
+    if not sanity["ok"]:
+        print(f"[bench] WARNING: the fit left the finite range: {sanity}", file=sys.stderr, flush=True)
 
     def evs(name):
         return [a.elapsed_time(b) * 1e-3 for a, b in timing.get(name, [])]
 
     per_step = {name: 1e3 * sum(evs(name)) / steps for name in timing}
     return {"elapsed": elapsed, "evs": evs, "per_step_ms": per_step, "dn": dn, "frames": frames, "positions0": positions0,
+            "sanity": sanity, "lr": lr,
             "lists_counters": lists_counters, "sparse_counters": sparse_counters, "T_total": T_total}
 
 
 def short_line(res, steps):
     """frames/s, ms per sweep and the per-kernel HIP-event times of a secondary measurement."""
     return {"value": res["T_total"] * steps / res["elapsed"], "unit": "frames/s", "steps": steps,
-            "ms_per_step": 1e3 * res["elapsed"] / steps,
+            "ms_per_step": 1e3 * res["elapsed"] / steps, "fit_sanity": res["sanity"],
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())}}
 
 
@@ -360,7 +377,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Simulator {size}x{size}x{T_total} (Z={Z}), K={K}, fp32: update_motion(epochs=1, "
-                                   f"batch {bs}, Adam lr 1e-5) + update_footprints(iter_c={args.iter_c}, gamma_c=0"
+                                   f"batch {bs}, Adam lr {res['lr']:.3g}) + update_footprints(iter_c={args.iter_c}, gamma_c=0"
                                    + (", live_spatial=True: K7 + K5 + all-reduce + K6)" if args.with_spatial else ")"),
                        "frames_per_gpu": T_loc,
                        "parallelism": f"frames sharded over {world} GPU(s), " +
@@ -376,10 +393,11 @@ def main():
             "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps,
                                       "K2_motion_kernels": 1e3 * (sum(k2) + sum(evs("motion_grad_lists"))) / args.steps},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())},
+            "fit_sanity": res["sanity"],
             "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key, ops.halo_voxels(sz)),
         }
         if world == 1 and not args.no_cpu_baseline and Z == 1:
-            line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy())
+            line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy(), res["lr"])
 
     # ---- secondary measurements (N = 1, default workload): never part of `value` -----------------------------------
     if world == 1 and not args.no_extras and not args.with_spatial and Z == 1 and size == 512 and K == 100:

@@ -282,6 +282,44 @@ __device__ __forceinline__ void make_taps(const Sample &sm, const Volume &vol, f
     }
 }
 
+// ---- where the taps of a box of voxels can fall ------------------------------------------------------------
+// Conservative range of a_d = 2 q_d over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0: every monomial is
+// monotone there, so a term's range follows from the sign of its coefficient (interval arithmetic on the ten terms).
+__device__ __forceinline__ void poly_range(const float *b, int d, const float (&lo)[3], const float (&hi)[3], bool hasz,
+                                           float &amin, float &amax) {
+    const float mlo[9] = {lo[0], lo[1], lo[2], lo[0] * lo[0], lo[1] * lo[1], lo[2] * lo[2], lo[0] * lo[1], lo[0] * lo[2], lo[1] * lo[2]};
+    const float mhi[9] = {hi[0], hi[1], hi[2], hi[0] * hi[0], hi[1] * hi[1], hi[2] * hi[2], hi[0] * hi[1], hi[0] * hi[2], hi[1] * hi[2]};
+    amin = amax = b[d];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const bool zterm = i == 2 || i == 5 || i == 7 || i == 8;
+        if (zterm && !hasz) continue;
+        const float c = b[3 * (i + 1) + d];
+        const float p = c * mlo[i], q = c * mhi[i];
+        amin += fminf(p, q), amax += fmaxf(p, q);
+    }
+    amin *= 2.0f, amax *= 2.0f;
+}
+
+// Integer range [a, c] that contains the base corner AND the second corner (base + 1) along axis d of every voxel of the
+// box, clamped to [-4, S + 5]: the source coordinate is a non-decreasing function of a_d, so its range follows from
+// poly_range; the margin is far above the fp32 rounding of either evaluation (a few roundings at magnitudes up to ~2S,
+// i.e. errors of order S * 1e-6 voxels).  False when the coordinates are NaN (such voxels gather zeros from the halo).
+__device__ __forceinline__ bool tap_range(const float *b, const Volume &vol, int d, const float (&lo)[3], const float (&hi)[3],
+                                          bool hasz, int &a, int &c) {
+    const int S = d == 0 ? vol.X : (d == 1 ? vol.Y : vol.Z);
+    const float h = d == 0 ? vol.hx1 : (d == 1 ? vol.hy1 : vol.hz1);
+    float amin, amax;
+    poly_range(b, d, lo, hi, hasz, amin, amax);
+    const float margin = 0.0625f + 4e-6f * (float)S;
+    const float ulo = unnormalise(normalise_axis<-1>(amin, vol, d), h) - margin;
+    const float uhi = unnormalise(normalise_axis<-1>(amax, vol, d), h) + margin;
+    if (!(ulo <= uhi)) return false;
+    a = (int)floorf(fminf(fmaxf(ulo, -4.0f), (float)S + 4.0f));
+    c = (int)floorf(fminf(fmaxf(uhi, -4.0f), (float)S + 4.0f)) + 1;
+    return true;
+}
+
 // Load the 30 coefficients of frame t from beta (10,3,T) into b[a*3+d].
 __device__ __forceinline__ void load_beta(const float *__restrict__ beta, int T, int t, float *b) {
 #pragma unroll

@@ -119,24 +119,6 @@ __global__ __launch_bounds__(256) void lists_axis_masks_kernel(const int *__rest
     }
 }
 
-// Conservative range of a_d = 2 q_d over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0:
-// every monomial is monotone there, so a term's range follows from the sign of its coefficient.
-__device__ __forceinline__ void poly_range(const float *b, int d, const float (&lo)[3], const float (&hi)[3], bool hasz,
-                                           float &amin, float &amax) {
-    const float mlo[9] = {lo[0], lo[1], lo[2], lo[0] * lo[0], lo[1] * lo[1], lo[2] * lo[2], lo[0] * lo[1], lo[0] * lo[2], lo[1] * lo[2]};
-    const float mhi[9] = {hi[0], hi[1], hi[2], hi[0] * hi[0], hi[1] * hi[1], hi[2] * hi[2], hi[0] * hi[1], hi[0] * hi[2], hi[1] * hi[2]};
-    amin = amax = b[d];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const bool zterm = i == 2 || i == 5 || i == 7 || i == 8;
-        if (zterm && !hasz) continue;
-        const float c = b[3 * (i + 1) + d];
-        const float p = c * mlo[i], q = c * mhi[i];
-        amin += fminf(p, q), amax += fmaxf(p, q);
-    }
-    amin *= 2.0f, amax *= 2.0f;
-}
-
 // One thread per (frame, tile): the tile's neuron list as NW 64-bit words.
 template <int NW>
 __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
@@ -161,22 +143,11 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int a = 0, c = 0;  // tap range along d; Z == 1: the taps sit in slice 0
-        if (d < 2 || hasz) {
-            float amin, amax;
-            poly_range(bt, d, lo, hi, hasz, amin, amax);
-            const float h = d == 0 ? vol.hx1 : (d == 1 ? vol.hy1 : vol.hz1);
-            // the source coordinate is a non-decreasing function of a; margin: both evaluations round a few times at
-            // magnitudes up to ~2S, i.e. errors of order S * 1e-6 voxels
-            const float margin = 0.0625f + 4e-6f * (float)S[d];
-            const float ulo = unnormalise(normalise_axis<-1>(amin, vol, d), h) - margin;
-            const float uhi = unnormalise(normalise_axis<-1>(amax, vol, d), h) + margin;
-            if (!(ulo <= uhi)) {  // NaN coordinates: every tap of the tile is pulled into the halo and reads zeros
+        if ((d < 2 || hasz) && !tap_range(bt, vol, d, lo, hi, hasz, a, c)) {
+            // NaN coordinates: every tap of the tile is pulled into the halo and reads zeros
 #pragma unroll
-                for (int w = 0; w < NW; ++w) m[w] = 0;
-                continue;
-            }
-            a = (int)floorf(fminf(fmaxf(ulo, -4.0f), (float)S[d] + 4.0f));
-            c = (int)floorf(fminf(fmaxf(uhi, -4.0f), (float)S[d] + 4.0f)) + 1;
+            for (int w = 0; w < NW; ++w) m[w] = 0;
+            continue;
         }
         const unsigned long long *LO = p.axis_masks + (axis_masks_offset(vol, d, 0) + (min(c, S[d]) + 1 < 0 ? 0 : min(c, S[d]) + 1)) * NW;
         const unsigned long long *HI = p.axis_masks + (axis_masks_offset(vol, d, 1) + min(max(a, 0), S[d] + 1)) * NW;

@@ -18,11 +18,8 @@ constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
 #ifndef DNMF_K2_UNROLL
 #define DNMF_K2_UNROLL 2
 #endif
-#ifndef DNMF_K2_PIPE
-#define DNMF_K2_PIPE 0
-#endif
-constexpr int K2_UNROLL = DNMF_K2_UNROLL;  // rows requested together; two such sets alternate
-static_assert(K2_ROWS % (2 * K2_UNROLL) == 0, "the row loop alternates two sets of K2_UNROLL rows");
+constexpr int K2_UNROLL = DNMF_K2_UNROLL;  // rows requested together
+static_assert(K2_ROWS % K2_UNROLL == 0, "the row loop takes K2_UNROLL rows at a time");
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -169,35 +166,8 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
             }
         };
         if (nrow == K2_ROWS) {
-#if DNMF_K2_PIPE
-            // two sets of K2_UNROLL rows, ping-pong: one set's taps are in flight while the other is blended
-            Req qa[K2_UNROLL], qb[K2_UNROLL];
-#pragma unroll
-            for (int j = 0; j < K2_UNROLL; ++j) request(x_first + j, qa[j]);
-#pragma unroll 1
-            for (int i = 0; i + 2 * K2_UNROLL < K2_ROWS; i += 2 * K2_UNROLL) {
-#pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + K2_UNROLL + j, qb[j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) consume(qa[j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + 2 * K2_UNROLL + j, qa[j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) consume(qb[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < K2_UNROLL; ++j) request(x_first + K2_ROWS - K2_UNROLL + j, qb[j]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < K2_UNROLL; ++j) consume(qa[j]);
-#pragma unroll
-            for (int j = 0; j < K2_UNROLL; ++j) consume(qb[j]);
-#else
-            // K2_UNROLL rows at a time: their taps are requested together, then blended
+            // K2_UNROLL rows at a time: their taps are requested together, then blended (keeping the next rows' taps in
+            // flight behind the blends of the current ones did not pay: 2.07 against 1.99 ms, tools/time_k2.py)
 #pragma unroll 1
             for (int i = 0; i < K2_ROWS; i += K2_UNROLL) {
                 Req q[K2_UNROLL];
@@ -206,7 +176,6 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
 #pragma unroll
                 for (int j = 0; j < K2_UNROLL; ++j) consume(q[j]);
             }
-#endif
         } else {
             for (int i = 0; i < nrow; ++i) {
                 Req q;
