@@ -24,8 +24,15 @@
 // Data flow.  Lane = voxel (16 lanes along y: the neuron-major footprint copy At is read in coalesced 64-byte
 // runs), four voxels per lane along x; tiles are walked along x, so a lane's (y,z) and the monomials without x
 // change only at the end of a tile row.  At is in the halo layout of common.hpp:
-// a tap outside the volume reads a zero, no masks or clamps along x and y.  Per listed neuron: 2 x NTAP/2 eight-byte
-// loads and NTAP FMAs per voxel give its warped values a_k, then r_k += a_k.y and G_kl += a_k.a_l for the listed
+// a tap outside the volume reads a zero, no masks or clamps along x and y.  Per listed neuron the warped values a_k of
+// the lane's voxels are NTAP FMAs on NTAP gathered taps.  Gathered straight from global memory those are 2 x NTAP/2
+// eight-byte loads per voxel with addresses that differ from lane to lane: ~16 cycles of a CU's texture path per
+// wave-instruction whatever its width (tools/gather_probe.hip), eight per neuron and tile, which kept that path 96 %
+// busy and set the kernel's time.  For Z == 1 the taps of a tile lie in a region of 20 rows x 24 floats of the footprint
+// image (lists_tilemask_kernel: the tile's tap box, first column aligned to 16 bytes): the wave copies that region of
+// each listed neuron into LDS with two sixteen-byte loads per lane and gathers from LDS (2.5 cycles per instruction);
+// tiles whose taps do not fit (a warp that scales a tile by more than ~15 %) and 3-D volumes keep the direct gathers.
+// Then r_k += a_k.y and G_kl += a_k.a_l for the listed
 // l >= k as per-lane partial sums.  While consecutive tiles have the same list the partial sums stay in registers;
 // when the list changes: a fixed DPP tree over the 64 lanes and one LDS add by the last lane into the wave's private
 // table of pattern slots.  LDS operations of one wave retire in order, so the sum is deterministic.  The table
@@ -37,12 +44,23 @@
 
 namespace dnmf {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef DNMF_K3N_WAVES
+#define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
+#endif
+
 constexpr int LISTS_NG = 4;      // neurons evaluated together (register slots); longer lists are cut into groups
 constexpr int LISTS_LGV = 2;      // log2 of the voxels per lane (consecutive x positions, interleaved by lane)
 constexpr int LISTS_VPL = 1 << LISTS_LGV;
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
 constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items per launch
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x 3800 words of LDS per workgroup
+// Staged gathers (Z == 1): the taps of a 16 x 16 tile lie in a region of RR rows x RC floats of a footprint image; a wave
+// copies that region of each listed neuron into LDS with sixteen-byte loads and gathers from there (see the kernel).
+constexpr int LISTS_RR = 20, LISTS_RC = 24;                 // 17 tap rows / columns + alignment of the first column + slack
+constexpr int LISTS_REGION = LISTS_RR * LISTS_RC;            // floats per neuron: 1,920 bytes, 120 sixteen-byte pieces
+static_assert(LISTS_RC == 24 && LISTS_REGION / 4 <= 128, "the piece arithmetic of stage_load assumes six pieces per row");
 
 struct ListParams {
     const float *At;       // (K, halo layout)
@@ -62,6 +80,8 @@ struct ListParams {
     const int *frame_ids;
     float *slab;  // (B, nchunks, nslot)
     unsigned long long *tile_masks;  // (B, ntiles, NW): the neuron list of every tile of every frame
+    int2 *tile_region;     // (B, ntiles): first halo row / first float of a halo row of the tile's tap region; x < 0: the
+                           // taps do not fit LISTS_RR x LISTS_RC (or Z > 1): direct gathers
     int nchunks, chunk_len;
     int lgx, lgz;  // tile = (LISTS_VPL << lgx) x 16 x (1 << lgz) voxels, lgx + lgz = 2
     int ntx, nty, ntz, ntiles;     // tile q = (qy * ntz + qz) * ntx + qx: walked along x
@@ -140,6 +160,8 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     unsigned long long m[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) m[w] = ~0ull;
+    int ta[3] = {0, 0, 0}, tc[3] = {0, 0, 0};
+    bool finite = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int a = 0, c = 0;  // tap range along d; Z == 1: the taps sit in slice 0
@@ -147,8 +169,10 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
             // NaN coordinates: every tap of the tile is pulled into the halo and reads zeros
 #pragma unroll
             for (int w = 0; w < NW; ++w) m[w] = 0;
+            finite = false;
             continue;
         }
+        ta[d] = a, tc[d] = c;
         const unsigned long long *LO = p.axis_masks + (axis_masks_offset(vol, d, 0) + (min(c, S[d]) + 1 < 0 ? 0 : min(c, S[d]) + 1)) * NW;
         const unsigned long long *HI = p.axis_masks + (axis_masks_offset(vol, d, 1) + min(max(a, 0), S[d] + 1)) * NW;
 #pragma unroll
@@ -156,10 +180,19 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) p.tile_masks[id * NW + w] = m[w];
+    // the region of a footprint image that holds every tap of the tile (the gathers clamp their base corner into
+    // [-HALO, S], the second corner is one further), origin pulled back so that the region stays inside the image
+    int2 reg = make_int2(-1, 0);
+    if (!hasz && finite && p.hl.Xp >= LISTS_RR && p.hl.rowf >= LISTS_RC && p.hl.Xp < 32768 && p.hl.rowf < 65536) {
+        const int ax = max(ta[0], -HALO), cx = min(tc[0], vol.X + 1), ay = max(ta[1], -HALO), cy = min(tc[1], vol.Y + 1);
+        const int r0 = min(ax + HALO, p.hl.Xp - LISTS_RR), c0 = min((ay + HALO) & ~3, p.hl.rowf - LISTS_RC);
+        if (cx >= ax && cy >= ay && cx + HALO - r0 < LISTS_RR && cy + HALO - c0 < LISTS_RC) reg = make_int2(r0, c0);
+    }
+    p.tile_region[id] = reg;
 }
 
 template <int NTAP, int NW, int FAST, bool F32OFF>
-__global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
+__global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gram_lists_kernel(ListParams p) {
     extern __shared__ float s_tab[];
     constexpr bool HASZ = NTAP == 8;
     constexpr int NPAIR = LISTS_NG * (LISTS_NG + 1) / 2;
@@ -182,6 +215,12 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
     float *tab = s_tab + (size_t)wave * p.nslot;
     for (int i = lane; i < p.nslot; i += 64) tab[i] = 0.0f;
     const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tab;  // LDS byte address
+    // this wave's LISTS_NG staging regions (NTAP == 4 only; 16-byte aligned: the tables before them are padded)
+    char *stage_lds = reinterpret_cast<char *>(s_tab + (((size_t)4 * p.nslot + 3) & ~(size_t)3)) +
+                      (size_t)wave * (LISTS_NG * LISTS_REGION * 4);
+    // piece e = lane + 64 j (j = 0, 1) of a region is row e / 6, floats 4 (e % 6) .. +3
+    const int piece_row = lane / (LISTS_RC / 4), piece_c4 = lane - piece_row * (LISTS_RC / 4);   // of piece `lane`
+    const int2 *__restrict__ regions = p.tile_region + (long)b * p.ntiles;
 
     const int lgx = p.lgx, lgz = p.lgz;
     const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & 15, lx = lane >> (lgz + 4);
@@ -267,15 +306,33 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
 #pragma unroll
     for (int wd = 0; wd < NW; ++wd) prev[wd] = 0;
 
-    for (int q = q_begin; q < q_end; ++q) {
+    // The lists and regions of 64 tiles at a time, one tile per lane (a per-tile load of these wave-uniform words would
+    // put a full memory round trip in front of every tile); a tile then takes its words from that lane.
+    for (int q0 = q_begin; q0 < q_end; q0 += 64) {
+      unsigned my_lo[NW], my_hi[NW];
+      int my_reg = -1;   // region origin packed as row << 16 | column (both below 65536: checked on the host), -1: none
+      {
+          const int ql = min(q0 + lane, q_end - 1);
+#pragma unroll
+          for (int wd = 0; wd < NW; ++wd) {
+              const unsigned long long m = masks[(long)ql * NW + wd];
+              my_lo[wd] = (unsigned)m, my_hi[wd] = (unsigned)(m >> 32);
+          }
+          if (!HASZ) {
+              const int2 rg = regions[ql];
+              my_reg = rg.x < 0 ? -1 : (rg.x << 16 | rg.y);
+          }
+      }
+      const int q1 = min(q0 + 64, q_end);
+      for (int q = q0; q < q1; ++q) {
+        const int jl = q - q0;
         unsigned long long msk[NW];
         int n = 0;  // wave-uniform
         bool same = true;
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) {
-            msk[wd] = masks[(long)q * NW + wd];
-            msk[wd] = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(msk[wd] >> 32)) << 32) |
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)msk[wd]);
+            msk[wd] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)my_hi[wd], jl) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)my_lo[wd], jl);
             n += __builtin_popcountll(msk[wd]);
             same = same && msk[wd] == prev[wd];
         }
@@ -293,9 +350,20 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
         const int qz = rest % p.ntz, qy = rest / p.ntz;
         const int y = (qy << 4) + ly, z = (qz << lgz) + lz;
         const bool yz_in = y < vol.Y && z < vol.Z;
+        // staged gathers for this tile?  (wave-uniform)
+        int reg_r0 = -1, reg_c0 = 0;
+        if (!HASZ) {
+            const int rg = __builtin_amdgcn_readlane(my_reg, jl);
+            reg_r0 = rg < 0 ? -1 : rg >> 16, reg_c0 = rg & 0xffff;
+        }
+        const bool staged = !HASZ && reg_r0 >= 0;
+        // byte offset of volume voxel (0,0) inside a staged region, and of the region inside a footprint image
+        const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
+        const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
 
         // ---- taps of this lane's four voxels: byte offsets of the two x-columns of the tap cell, weights ------------
-        unsigned off[LISTS_VPL][NTAP / 2];   // [.][dx + 2 dz]: the (y, y+1) pair is one eight-byte load
+        unsigned off[LISTS_VPL][NTAP / 2];   // [.][dx + 2 dz]: the (y, y+1) pair is one eight-byte load; a staged tile
+                                             // keeps the LDS byte offset of the base corner inside a region in [.][0]
         float w[LISTS_VPL][NTAP];            // [.][dy + 2 (dx + 2 dz)]
         float yv[LISTS_VPL];
         const int xt = qx << (lgx + LISTS_LGV);  // first x of the tile
@@ -336,6 +404,10 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
                         off[v][dx + 2 * dz] = o0 + zo[dz] + (dx ? (unsigned)hl.row4 : 0u);
+                        // (a voxel beyond the volume is not covered by the tile's region: it reads the region's first
+                        // float, times zero)
+                        if (!HASZ && staged && dx == 0)
+                            off[v][0] = in ? (unsigned)fmaf(fx, (float)(4 * LISTS_RC), fmaf(fy, 4.0f, lds_origin)) : 0u;
                         const float wxz = HASZ ? __fmul_rn(wx[dx], wzm[dz]) : wx[dx];
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy) w[v][dy + 2 * (dx + 2 * dz)] = in ? __fmul_rn(wxz, wy[dy]) : 0.0f;
@@ -371,6 +443,41 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
                 a[v] = s;
             }
         };
+        // staged: the region of neuron k into staging slot i (two sixteen-byte pieces per lane, 120 in all) ...
+        auto stage_load = [&](int k, f32x4 (&piece)[2]) {
+            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane + reg_goff;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // piece lane + 64: 64 = 10 rows + 4 pieces further on
+                const int c4 = piece_c4 + (j ? 4 : 0), row = piece_row + (j ? 10 : 0) + (c4 >= LISTS_RC / 4 ? 1 : 0);
+                unsigned o = (unsigned)(row * hl.row4 + (c4 >= LISTS_RC / 4 ? c4 - LISTS_RC / 4 : c4) * 16);
+                asm("" : "+v"(o));
+                piece[j] = (j == 0 || lane + 64 < LISTS_REGION / 4) ? *reinterpret_cast<const f32x4 *>(Ak + o)
+                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto stage_store = [&](int i, const f32x4 (&piece)[2]) {
+            char *dst = stage_lds + i * (LISTS_REGION * 4);
+            *reinterpret_cast<f32x4 *>(dst + lane * 16) = piece[0];
+            if (lane + 64 < LISTS_REGION / 4) *reinterpret_cast<f32x4 *>(dst + (lane + 64) * 16) = piece[1];
+        };
+        // ... and the warped values of the lane's voxels from there
+        auto eval_staged = [&](int i, float (&a)[LISTS_VPL]) {
+            const char *src0 = stage_lds + i * (LISTS_REGION * 4);
+#pragma unroll
+            for (int v = 0; v < LISTS_VPL; ++v) {
+                const char *src = src0 + off[v][0];
+                float s = 0.0f;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float s0 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC));
+                    const float s1 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC) + 4);
+                    s = fmaf(s0, w[v][2 * dx], s);
+                    s = fmaf(s1, w[v][2 * dx + 1], s);
+                }
+                a[v] = s;
+            }
+        };
         auto dot4 = [&](const float (&a)[LISTS_VPL], const float (&cc)[LISTS_VPL], float init) {
             float s = init;
 #pragma unroll
@@ -390,8 +497,22 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
             auto go = [&](auto nn) {
                 constexpr int N = decltype(nn)::value;
                 float a[N][LISTS_VPL];
+                if (staged) {
+                    // the regions are requested two neurons at a time (four would hold 32 registers for the pieces)
 #pragma unroll
-                for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
+                    for (int i0 = 0; i0 < N; i0 += 2) {
+                        f32x4 piece[2][2];
+#pragma unroll
+                        for (int i = i0; i < N && i < i0 + 2; ++i) stage_load(ks[i], piece[i - i0]);
+#pragma unroll
+                        for (int i = i0; i < N && i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; ++i) eval_staged(i, a[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
+                }
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -460,6 +581,7 @@ __global__ __launch_bounds__(256) void warp_gram_lists_kernel(ListParams p) {
                 }
             }
         }
+      }
     }
     flush();
 
@@ -648,7 +770,7 @@ size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z,
     if (nslot <= 0 || B <= 0 || K <= 0 || K > 64 * LISTS_MAXW || X <= 0 || Y <= 0 || Z <= 0) return 0;
     int lgx, lgz, ntx, nty, ntz, ntiles;
     lists_tile_shape(make_volume(X, Y, Z), lgx, lgz, ntx, nty, ntz, ntiles);
-    return lists_slab_bytes(nslot, B) + (size_t)B * ntiles * lists_words(K) * sizeof(unsigned long long);
+    return lists_slab_bytes(nslot, B) + (size_t)B * ntiles * (lists_words(K) * sizeof(unsigned long long) + sizeof(int2));
 }
 
 int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, const void *axis_masks, int nslot, int K,
@@ -686,7 +808,10 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
     const long nitems = (long)p.nchunks * B;
     const unsigned nwg = (unsigned)((nitems + 3) / 4);
     const int nw = lists_words(K);
-    const size_t lds = (size_t)4 * nslot * sizeof(float);
+    p.tile_region = reinterpret_cast<int2 *>(p.tile_masks + (size_t)B * p.ntiles * lists_words(K));
+    // four slot tables (padded to 16 bytes), then for Z == 1 the four waves' staging regions
+    const size_t lds = (((size_t)4 * nslot + 3) & ~(size_t)3) * sizeof(float) +
+                       (Z == 1 ? (size_t)4 * LISTS_NG * LISTS_REGION * sizeof(float) : 0);
     if (Z > 1) {
         if (nw == 1) launch_lists_t<8, 1>(p, nwg, lds, st);
         else if (nw == 2) launch_lists_t<8, 2>(p, nwg, lds, st);

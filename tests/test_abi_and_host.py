@@ -60,9 +60,10 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert lib.dnmf_halo_row(512, 1) == 544 and lib.dnmf_halo_row(5, 3) == 32     # rows start on 128-byte lines
     assert lib.dnmf_halo_voxels(512, 512, 1) == 516 * 544 and lib.dnmf_halo_voxels(4, 5, 3) == 8 * 32
     assert lib.dnmf_lists_axis_masks_bytes(512, 512, 1, 100) == 2 * (512 + 512 + 1 + 6) * 2 * 8
-    # slot tables (5 chunks per frame at B = 4000; rounded up to 256 bytes), then one 2-word list per frame and tile
+    # slot tables (5 chunks per frame at B = 4000; rounded up to 256 bytes), then one 2-word list and one region record
+    # per frame and tile
     slab = (4000 * 5 * 461 * 4 + 255) // 256 * 256
-    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 100, 512, 512, 1, 4000) == slab + 4000 * 1024 * 2 * 8
+    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 100, 512, 512, 1, 4000) == slab + 4000 * 1024 * (2 * 8 + 8)
     rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, addr, 5000, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr,
                                       addr, 1 << 20, None, None)
     assert rc == -3 and b"pattern slots" in lib.dnmf_last_error()
