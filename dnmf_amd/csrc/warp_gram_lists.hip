@@ -228,6 +228,17 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     const int q_end = min(q_begin + p.chunk_len, p.ntiles);
     const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
     unsigned long long n_eval = 0, n_pair = 0;  // wave-uniform
+#ifdef DNMF_K3N_STAMPS
+    // diagnostic build only (tools/k3n_stamps.py): wave cycles per section of the tile loop into counters[2..7]
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define DNMF_STAMP(i)                                                     \
+    {                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        st_acc[i] += now_ - st_last, st_last = now_;                      \
+    }
+#else
+#define DNMF_STAMP(i)
+#endif
 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -337,7 +348,9 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             same = same && msk[wd] == prev[wd];
         }
         if (n == 0) continue;
+        DNMF_STAMP(0)   // tile bookkeeping (and, in this accounting, the whole of a preceding long-list tile)
         if (!same || n > LISTS_NG) flush();
+        DNMF_STAMP(1)   // reductions of a finished run
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) prev[wd] = n > LISTS_NG ? 0 : msk[wd];
 
@@ -422,6 +435,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             taps(std::true_type{});
         else
             taps(std::false_type{});
+        DNMF_STAMP(2)   // coordinates, weights, frame loads issued
 
         auto eval = [&](int k, float (&a)[LISTS_VPL]) {
             const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane;
@@ -507,6 +521,10 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #pragma unroll
                         for (int i = i0; i < N && i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
                     }
+#ifdef DNMF_K3N_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                    DNMF_STAMP(3)   // regions requested, arrived (with the frame values), stored
 #pragma unroll
                     for (int i = 0; i < N; ++i) eval_staged(i, a[i]);
                 } else {
@@ -531,6 +549,11 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #pragma unroll
             for (int i = 0; i < LISTS_NG; ++i) run_k[i] = ks[i];
             run_n = n;
+#ifdef DNMF_K3N_STAMPS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::"v"(acc_r[0]), "v"(acc_p[0]));
+#endif
+            DNMF_STAMP(4)   // taps from LDS (or direct gathers), per-lane sums
             continue;
         }
         // long lists: groups of LISTS_NG neurons, every group against itself and against every later group; reduced
@@ -593,6 +616,10 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     if (p.counters && lane == 0) {
         atomicAdd(&p.counters[0], n_eval);
         atomicAdd(&p.counters[1], n_pair);
+#ifdef DNMF_K3N_STAMPS
+        DNMF_STAMP(5)
+        for (int i = 0; i < 6; ++i) atomicAdd(&p.counters[2 + i], st_acc[i]);
+#endif
     }
 }
 
