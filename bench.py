@@ -332,7 +332,7 @@ def main():
             # K3n has no matrix-pipe work; its floor is the traffic it cannot avoid: every frame once, the footprints
             # once (they stay in L2 / MALL across frames), G and r once
             abytes = 4.0 * P * T_loc + 4.0 * P * K + 4.0 * T_loc * (K * K + K)
-            n_eval, n_pair = (float(v) / len(k3n) for v in res["lists_counters"])
+            n_eval, n_pair = (float(v) / len(k3n) for v in res["lists_counters"][:2])
             roof = {"kernel": f"warp_gram_lists_kernel<{ntap},{1 if K <= 64 else 2 if K <= 128 else 4},1,true> (K3n: per "
                               "256-voxel tile only the neurons whose non-zero box the tile's taps can reach; vector ALU, no "
                               "MFMA) + lists_tilemask_kernel (the tiles' neuron lists), one API call",
@@ -349,7 +349,7 @@ def main():
         elif sparse:
             # flops of the products that were not skipped, from the kernel's own counters: an MFMA is
             # 16x16x4 MACs; a (block, k-step) gather is 64 lanes x (taps + rhs) FMAs
-            n_mfma, n_blend = (float(v) / len(k3s) for v in res["sparse_counters"])
+            n_mfma, n_blend = (float(v) / len(k3s) for v in res["sparse_counters"][:2])
             flops = n_mfma * 2048 + n_blend * 64 * 2 * (ntap + 1) + T_loc * P * 82  # + warp geometry (82 flops/voxel)
             kname = "warp_gram_lt_kernel" if ops.SPARSE_VARIANT == "table" else "warp_gram_sparse_kernel"
             roof = {"kernel": kname + " (K3s, v_mfma_f32_16x16x4_f32, exact-zero blocks skipped)",

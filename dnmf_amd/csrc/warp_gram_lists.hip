@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             const int rg = __builtin_amdgcn_readlane(my_reg, jl);
             reg_r0 = rg < 0 ? -1 : rg >> 16, reg_c0 = rg & 0xffff;
         }
-        const bool staged = !HASZ && reg_r0 >= 0;
+        const bool staged = !HASZ && reg_r0 >= 0 && n <= LISTS_NG;   // long lists keep the direct gathers (and their offsets)
         // byte offset of volume voxel (0,0) inside a staged region, and of the region inside a footprint image
         const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
         const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
