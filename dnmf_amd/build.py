@@ -1,6 +1,6 @@
 """Build libdnmf_hip.so (gfx950) in-tree with hipcc.
 
-    python -m dnmf_amd.build [--force] [--out PATH] [-DNAME=VALUE ...]
+    python -m dnmf_amd.build [--force] [--out PATH] [-DNAME=VALUE | -fFLAG | -mFLAG ...]
 
 ``--out`` / ``-D``: a kernel-variant build beside the product library (timing studies; ``DNMF_LIB=PATH`` selects it).
 
@@ -55,4 +55,4 @@ def build_library(force: bool = False, verbose: bool = True, out: str | None = N
 if __name__ == "__main__":
     args = sys.argv[1:]
     out = args[args.index("--out") + 1] if "--out" in args else None
-    print(build_library(force="--force" in args, out=out, defines=[a for a in args if a.startswith("-D")]))
+    print(build_library(force="--force" in args, out=out, defines=[a for a in args if a.startswith(("-D", "-f", "-m"))]))

@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
     unsigned long long n_eval = 0, n_pair = 0;  // wave-uniform
 #ifdef DNMF_K3N_STAMPS
-    // diagnostic build only (tools/k3n_stamps.py): wave cycles per section of the tile loop into counters[2..7]
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    // diagnostic build only (tools/k3n_stamps.py): wave cycles per section of the tile loop into counters[2..8], then
+    // the number of non-empty tiles, of long-list tiles and of flushed runs
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define DNMF_STAMP(i)                                                     \
     {                                                                     \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
@@ -251,7 +252,11 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     };
     // slot of a pair: a scalar load issued before the arithmetic that precedes its use
     auto pair_slot_of = [&](int k, int l) {
+#ifdef DNMF_K3N_ABL_SLOT
+        return K + ((max(k, 0) * 7 + max(l, 0)) & 255);   // timing ablation (tools/k3n_stamps.py): wrong sums, no table lookup
+#else
         return __builtin_amdgcn_readfirstlane(p.pair_slot[max(k, 0) * K + max(l, 0)]);
+#endif
     };
     // the lowest LISTS_NG set bits of a list (-1 past its end); `rem` loses them
     auto take_ids = [&](unsigned long long (&rem)[NW], int (&ks)[LISTS_NG]) {
@@ -348,7 +353,10 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             same = same && msk[wd] == prev[wd];
         }
         if (n == 0) continue;
-        DNMF_STAMP(0)   // tile bookkeeping (and, in this accounting, the whole of a preceding long-list tile)
+        DNMF_STAMP(0)   // tile bookkeeping
+#ifdef DNMF_K3N_STAMPS
+        st_acc[7] += 1, st_acc[8] += n > LISTS_NG, st_acc[9] += (!same || n > LISTS_NG) && run_n != 0;   // tiles, long lists, flushes
+#endif
         if (!same || n > LISTS_NG) flush();
         DNMF_STAMP(1)   // reductions of a finished run
 #pragma unroll
@@ -427,7 +435,11 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                     }
                 unsigned yo = in ? yo0 + (unsigned)v * ystep : 0u;
                 asm("" : "+v"(yo));
+#ifdef DNMF_K3N_ABL_FRAME   // timing ablation: no frame loads
+                const float val = __builtin_bit_cast(float, yo);
+#else
                 const float val = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(yb) + yo);
+#endif
                 yv[v] = in ? val : 0.0f;
             }
         };
@@ -516,10 +528,12 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #pragma unroll
                     for (int i0 = 0; i0 < N; i0 += 2) {
                         f32x4 piece[2][2];
+#ifndef DNMF_K3N_ABL_STAGE   // timing ablation: taps from whatever the LDS holds
 #pragma unroll
                         for (int i = i0; i < N && i < i0 + 2; ++i) stage_load(ks[i], piece[i - i0]);
 #pragma unroll
                         for (int i = i0; i < N && i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+#endif
                     }
 #ifdef DNMF_K3N_STAMPS
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -604,6 +618,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                 }
             }
         }
+        DNMF_STAMP(6)   // a long-list tile, after its coordinates
       }
     }
     flush();
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         atomicAdd(&p.counters[1], n_pair);
 #ifdef DNMF_K3N_STAMPS
         DNMF_STAMP(5)
-        for (int i = 0; i < 6; ++i) atomicAdd(&p.counters[2 + i], st_acc[i]);
+        for (int i = 0; i < 10; ++i) atomicAdd(&p.counters[2 + i], st_acc[i]);
 #endif
     }
 }

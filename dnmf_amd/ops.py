@@ -388,7 +388,7 @@ def warp_gram_rhs_lists(layout, K, sz, beta, times, frames, frame_ids=None, work
     counters = None
     if TIMING is not None:
         if LISTS_COUNTERS is None:
-            LISTS_COUNTERS = torch.zeros(8, dtype=torch.int64, device=dev)   # [2:] only in stamp builds
+            LISTS_COUNTERS = torch.zeros(12, dtype=torch.int64, device=dev)   # [2:] only in stamp builds
         counters = LISTS_COUNTERS
     with _timed("warp_gram_rhs_lists"):
         rc = lib.dnmf_warp_gram_rhs_lists(

@@ -38,11 +38,13 @@ def main():
     c = ops.LISTS_COUNTERS.tolist()
     (a, b) = ops.TIMING["warp_gram_rhs_lists"][-1]
     ms = a.elapsed_time(b)
-    tot = sum(c[2:])
+    tot = sum(c[2:9])
     names = ["tile bookkeeping", "reductions of finished runs", "coordinates / weights / frame loads issued",
-             "regions requested, arrived, stored", "taps from LDS + per-lane sums", "rest (prologue, table write-back)"]
+             "regions requested, arrived, stored", "taps from LDS + per-lane sums", "rest (prologue, table write-back)",
+             "long-list tiles after their coordinates"]
     print(f"launch {ms:.3f} ms; evals/frame {c[0] / T:.0f}; wave-cycles total {tot:.3e}")
-    for n, v in zip(names, c[2:]):
+    print(f"non-empty tiles per frame {c[9] / T:.0f} of 1024; long lists {c[10] / T:.1f}; flushed runs {c[11] / T:.0f}")
+    for n, v in zip(names, c[2:9]):
         print(f"  {n:45s} {100.0 * v / max(tot, 1):5.1f} %   {v / (T * 1024):8.0f} cycles per tile")
 
 
