@@ -7,15 +7,18 @@
 // to the lowest voxel index, cKDTree's choice there is unspecified.
 //
 // Search.  The warped position s(v) is a quadratic polynomial of the voxel v, so s(a) - s(b) = J((a+b)/2) (a - b)
-// EXACTLY, J the Jacobian; with m a lower bound of the smallest singular value of J over the volume,
-// |s(a) - s(b)| >= m |a - b|.  For a lattice point g and ANY voxel v0 at distance d0 = |s(v0) - g| the nearest voxel
-// v* has |s(v*) - g| <= d0, hence |v* - v0| <= 2 d0 / m: it lies in the window of that radius around v0.  The kernel
-// gets v0 from a few fixed-point steps of v <- v + (g - s(v)) (S-1)/S, searches that window (49 candidates for a
-// near-identity warp of a 2-D volume instead of all P) and marks the lattice points whose window would exceed
-// IW_RMAX -- or for which m <= 0: a warp that folds -- for the exhaustive kernel, which is the O(P) per point search
-// of round 1 and now runs only for those.  Both kernels evaluate s(v) with the same fp32 sequence and compare the
-// same float64 distances, so the result is the exhaustive search's bit for bit (the rounding of s in fp32 is
-// covered by a slack in the radius).
+// EXACTLY, J the Jacobian; with m a lower bound of the smallest singular value of J over the volume (one value per
+// frame, iwarp_stretch_kernel), |s(a) - s(b)| >= m |a - b| for a, b inside the volume.  For a lattice point g the kernel
+// takes a few fixed-point steps v <- v + (g - s(v)) (S-1)/S towards the pre-image of g, clamps v into the volume and
+// measures what is left, rho = |s(v) - g|.  The voxels of the lattice cell around v are candidates; d0 = the smallest
+// of their distances to g.  The nearest voxel v* has |s(v*) - g| <= d0, hence m |v* - v| <= |s(v*) - s(v)| <= d0 + rho:
+// it lies in the box of radius r = (d0 + rho)/m around the CONTINUOUS point v -- for a near-identity warp r < 1 and the
+// box is the cell just searched (4 candidates in 2-D, 8 in 3-D; the first version of this search centred the window on
+// a voxel, radius 2 d0/m: 25 candidates).  Only when the box sticks out of the cell is it searched as a whole.  Lattice
+// points whose box would exceed IW_RMAX -- or frames with m <= 0: a warp that folds -- are marked for the exhaustive
+// kernel, the O(P) per point search of round 1.  Both kernels evaluate s(voxel) with the same fp32 sequence and
+// compare the same float64 distances, lowest voxel index first among equals, so the result is the exhaustive search's
+// bit for bit (the rounding of s in fp32 is covered by a slack in the radius).
 #include "common.hpp"
 
 namespace dnmf {
@@ -24,15 +27,22 @@ constexpr int IW_TILE = 1024;
 constexpr int IW_RMAX = 24;   // largest window radius searched in place (49 x 49 (x Z) candidates)
 
 // warped position of voxel (x,y,z) scaled by sz (not sz-1), fp32 like the reference (flow_ is a float32 tensor there)
-__device__ __forceinline__ void iwarp_position(const float *bt, const Volume &vol, int x, int y, int z, float &sx, float &sy,
-                                               float &sz) {
-    const float xf = (float)x, yf = (float)y, zf = (float)z;
-    const bool hz = vol.Z > 1;
-    const float nx = hz ? grid_n<true>(bt, vol, 0, xf, yf, zf) : grid_n<false>(bt, vol, 0, xf, yf, 0.0f);
-    const float ny = hz ? grid_n<true>(bt, vol, 1, xf, yf, zf) : grid_n<false>(bt, vol, 1, xf, yf, 0.0f);
+template <bool HASZ>
+__device__ __forceinline__ void iwarp_position_t(const float *bt, const Volume &vol, int x, int y, int z, float &sx,
+                                                 float &sy, float &sz) {
+    const float xf = (float)x, yf = (float)y, zf = HASZ ? (float)z : 0.0f;
+    const float nx = grid_n<HASZ>(bt, vol, 0, xf, yf, zf);
+    const float ny = grid_n<HASZ>(bt, vol, 1, xf, yf, zf);
     sx = __fmul_rn(__fmul_rn(__fadd_rn(nx, 1.0f), 0.5f), (float)vol.X);
     sy = __fmul_rn(__fmul_rn(__fadd_rn(ny, 1.0f), 0.5f), (float)vol.Y);
-    sz = hz ? __fmul_rn(__fmul_rn(__fadd_rn(grid_n<true>(bt, vol, 2, xf, yf, zf), 1.0f), 0.5f), (float)vol.Z) : 0.0f;
+    sz = HASZ ? __fmul_rn(__fmul_rn(__fadd_rn(grid_n<HASZ>(bt, vol, 2, xf, yf, zf), 1.0f), 0.5f), (float)vol.Z) : 0.0f;
+}
+__device__ __forceinline__ void iwarp_position(const float *bt, const Volume &vol, int x, int y, int z, float &sx, float &sy,
+                                               float &sz) {
+    if (vol.Z > 1)
+        iwarp_position_t<true>(bt, vol, x, y, z, sx, sy, sz);
+    else
+        iwarp_position_t<false>(bt, vol, x, y, z, sx, sy, sz);
 }
 
 // Lower bound of |q(a) - q(b)| / |a - b| over the volume for the quadratic map q = basis . beta (the un-scaled warp;
@@ -79,69 +89,107 @@ __device__ double iwarp_min_stretch(const float *b, const Volume &vol) {
     return m == m ? m : 0.0;   // NaN coefficients: no bound
 }
 
-// One thread per lattice point: seed, window search; todo[g] = 1 where the window would be too large.
+// 1/m of every frame of the call, rounded up; +inf where there is no usable bound (every point of such a frame is
+// then marked for the exhaustive search)
+__global__ void iwarp_stretch_kernel(const float *__restrict__ beta, int T, const int *__restrict__ times, int B, Volume vol,
+                                     float *__restrict__ inv_stretch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float bt[30];
+    load_beta(beta, T, times[b], bt);
+    const double m = iwarp_min_stretch(bt, vol);
+    inv_stretch[b] = m > 1e-3 ? (float)(1.0 / m) * 1.000001f : __builtin_inff();
+}
+
+// One thread per lattice point: pre-image estimate, its cell, the box if it is larger; todo[g] = 1 where the box would
+// be too large.
+template <bool HASZ>
 __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__restrict__ frames, long ldf,
                                                                  const int *__restrict__ frame_ids, Volume vol,
                                                                  const float *__restrict__ beta, int T,
-                                                                 const int *__restrict__ times, float *__restrict__ out,
+                                                                 const int *__restrict__ times,
+                                                                 const float *__restrict__ inv_stretch, float *__restrict__ out,
                                                                  long ldo, unsigned char *__restrict__ todo) {
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= vol.P) return;
-    const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
-    float bt[30];
-    load_beta(beta, T, times[b], bt);
-    const double m = iwarp_min_stretch(bt, vol);
     unsigned char *flag = todo + (long)b * vol.P + g;
-    if (!(m > 1e-3)) {
+    const float inv_m = inv_stretch[b];
+    if (!(inv_m < 1e3f)) {
         *flag = 1;
         return;
     }
+    const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
+    float bt[30], b2[30];
+    load_beta(beta, T, times[b], bt);
+    double_beta(bt, b2);
     int gx, gy, gz;
     voxel_xyz(g, vol, gx, gy, gz);
-    const bool hz = vol.Z > 1;
-    // seed: fixed-point steps on the continuous map, then the nearest voxel inside the volume
-    const float kx = vol.sx1 / (float)vol.X, ky = vol.sy1 / (float)vol.Y, kz = hz ? vol.sz1 / (float)vol.Z : 1.0f;
-    float vx = gx * kx, vy = gy * ky, vz = hz ? gz * kz : 0.0f;
-    for (int it = 0; it < 4; ++it) {
-        float s[3] = {0.0f, 0.0f, 0.0f};
-        float b2[30];
-        double_beta(bt, b2);
-        for (int d = 0; d < (hz ? 3 : 2); ++d) {
-            const float a = hz ? poly_a<true>(b2, d, monomials<true>(vx, vy, vz)) : poly_a<false>(b2, d, monomials<false>(vx, vy, 0.0f));
-            s[d] = 0.5f * a / (d == 0 ? kx : (d == 1 ? ky : kz));   // q S/(S-1)
-        }
-        vx += (gx - s[0]) * kx, vy += (gy - s[1]) * ky;
-        if (hz) vz += (gz - s[2]) * kz;
+    constexpr int ND = HASZ ? 3 : 2;
+    // s(v) for a continuous v: q S/(S-1) (dNMF.py:81-83); k = (S-1)/S.  (Any rounding here only moves the estimate v:
+    // what is left of g - s(v) is measured below and enters the radius.)
+    const float k[3] = {vol.sx1 / (float)vol.X, vol.sy1 / (float)vol.Y, HASZ ? vol.sz1 / (float)vol.Z : 1.0f};
+    const float hk[3] = {0.5f * (float)vol.X / vol.sx1, 0.5f * (float)vol.Y / vol.sy1, HASZ ? 0.5f * (float)vol.Z / vol.sz1 : 0.5f};
+    const float gf[3] = {(float)gx, (float)gy, (float)gz};
+    float v[3] = {gf[0] * k[0], gf[1] * k[1], HASZ ? gf[2] * k[2] : 0.0f};
+    float res[3] = {0.0f, 0.0f, 0.0f};   // g - s(v)
+    auto residual = [&]() {
+        const Monomials<HASZ> mo = monomials<HASZ>(v[0], v[1], v[2]);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) res[d] = gf[d] - poly_a<HASZ>(b2, d, mo) * hk[d];
+    };
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        residual();
+#pragma unroll
+        for (int d = 0; d < ND; ++d) v[d] += res[d] * k[d];
     }
-    const int x0 = min(max((int)rintf(fminf(fmaxf(vx, -1.0f), (float)vol.X)), 0), vol.X - 1);
-    const int y0 = min(max((int)rintf(fminf(fmaxf(vy, -1.0f), (float)vol.Y)), 0), vol.Y - 1);
-    const int z0 = hz ? min(max((int)rintf(fminf(fmaxf(vz, -1.0f), (float)vol.Z)), 0), vol.Z - 1) : 0;
-    float sx, sy, sz;
-    iwarp_position(bt, vol, x0, y0, z0, sx, sy, sz);
-    const double ex = (double)sx - gx, ey = (double)sy - gy, ez = (double)sz - gz;
-    const double d0 = sqrt(ex * ex + ey * ey + ez * ez);
-    // fp32 rounding of the positions: a few units in the last place at magnitudes up to the volume size
-    const double eps = 1e-4 + 1e-5 * (double)max(vol.X, max(vol.Y, vol.Z));
-    const double rr = (2.0 * d0 + 2.0 * eps) / m;
-    if (!(rr < (double)IW_RMAX)) {   // also NaN
+    // into the volume (the stretch bound holds between points of the volume); a NaN becomes 0 and ends in a NaN radius
+    const int S[3] = {vol.X, vol.Y, vol.Z};
+#pragma unroll
+    for (int d = 0; d < ND; ++d) v[d] = fminf(fmaxf(v[d], 0.0f), (float)(S[d] - 1));
+    residual();
+    const float rho = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
+    // the cell of v
+    int c0[3], c1[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        c0[d] = d < ND ? min((int)v[d], max(S[d] - 2, 0)) : 0;
+        c1[d] = d < ND ? min(c0[d] + 1, S[d] - 1) : 0;
+    }
+    double best = 1e300;
+    long arg = 0;
+    auto candidate = [&](int x, int yy, int z) {
+        float sx, sy, sz;
+        iwarp_position_t<HASZ>(bt, vol, x, yy, z, sx, sy, sz);
+        const double dx = (double)sx - gx, dy = (double)sy - gy, dz = (double)sz - gz;
+        const double d = dx * dx + dy * dy + dz * dz;
+        const long idx = ((long)x * vol.Y + yy) * vol.Z + z;
+        if (d < best || (d == best && idx < arg)) best = d, arg = idx;   // ties: the lowest voxel index, as in the full search
+    };
+    for (int x = c0[0]; x <= c1[0]; ++x)
+        for (int yy = c0[1]; yy <= c1[1]; ++yy)
+            for (int z = c0[2]; z <= c1[2]; ++z) candidate(x, yy, z);
+    // fp32 rounding of the positions (lattice and continuous evaluation): a few units in the last place at magnitudes
+    // up to the volume size; the radius itself is evaluated in fp32, rounded generously upwards
+    const float eps = 1e-4f + 1e-5f * (float)max(vol.X, max(vol.Y, vol.Z));
+    const float r = ((sqrtf((float)best) + rho) * 1.00001f + 3.0f * eps) * inv_m + 1e-3f;
+    if (!(r < (float)IW_RMAX)) {   // also NaN
         *flag = 1;
         return;
     }
-    const int R = (int)rr + 1;
-    double best = 1e300;
-    long arg = 0;
-    const int xa = max(x0 - R, 0), xb = min(x0 + R, vol.X - 1);
-    const int ya = max(y0 - R, 0), yb = min(y0 + R, vol.Y - 1);
-    const int za = max(z0 - R, 0), zb = min(z0 + R, vol.Z - 1);
-    for (int x = xa; x <= xb; ++x)           // ascending voxel index: a tie goes to the lowest, as in the full search
-        for (int yy = ya; yy <= yb; ++yy)
-            for (int z = za; z <= zb; ++z) {
-                iwarp_position(bt, vol, x, yy, z, sx, sy, sz);
-                const double dx = (double)sx - gx, dy = (double)sy - gy, dz = (double)sz - gz;
-                const double d = dx * dx + dy * dy + dz * dz;
-                if (d < best) best = d, arg = ((long)x * vol.Y + yy) * vol.Z + z;
-            }
+    int lo[3], hi[3];
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = d < ND ? max((int)ceilf(v[d] - r), 0) : 0;
+        hi[d] = d < ND ? min((int)floorf(v[d] + r), S[d] - 1) : 0;
+        inside = inside && lo[d] >= c0[d] && hi[d] <= c1[d];
+    }
+    if (!inside)
+        for (int x = lo[0]; x <= hi[0]; ++x)
+            for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                for (int z = lo[2]; z <= hi[2]; ++z) candidate(x, yy, z);
     out[(long)b * ldo + g] = y[arg];
     *flag = 0;
 }
@@ -197,9 +245,12 @@ __global__ void count_flags_kernel(const unsigned char *__restrict__ todo, long 
 
 extern "C" {
 
+// one flag byte per lattice point and frame, then one float per frame
+static size_t iwarp_flag_bytes(int X, int Y, int Z, int B) { return ((size_t)X * Y * Z * B + 7) / 8 * 8; }
+
 size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B) {
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
-    return (size_t)X * Y * Z * B;
+    return iwarp_flag_bytes(X, Y, Z, B) + sizeof(float) * (size_t)B;
 }
 
 int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta, int T,
@@ -220,8 +271,14 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
         hipError_t e = hipMemsetAsync(todo, 1, (size_t)vol.P * B, st);
         DNMF_REQUIRE(e == hipSuccess, (int)e, "dnmf_image_iwarp: hipMemsetAsync: %s", hipGetErrorString(e));
     } else {
-        hipLaunchKernelGGL(image_iwarp_window_kernel, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times, out,
-                           ldo, todo);
+        float *stretch = reinterpret_cast<float *>(todo + iwarp_flag_bytes(X, Y, Z, B));
+        hipLaunchKernelGGL(iwarp_stretch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, beta, T, times, B, vol, stretch);
+        if (Z > 1)
+            hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
+                               times, stretch, out, ldo, todo);
+        else
+            hipLaunchKernelGGL(image_iwarp_window_kernel<false>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
+                               times, stretch, out, ldo, todo);
     }
     if (fallback_count) {
         const long n = vol.P * B;
