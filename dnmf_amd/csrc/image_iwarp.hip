@@ -92,14 +92,19 @@ __device__ double iwarp_min_stretch(const float *b, const Volume &vol) {
 // 1/m of every frame of the call, rounded up; +inf where there is no usable bound (every point of such a frame is
 // then marked for the exhaustive search)
 __global__ void iwarp_stretch_kernel(const float *__restrict__ beta, int T, const int *__restrict__ times, int B, Volume vol,
-                                     float *__restrict__ inv_stretch) {
+                                     float *__restrict__ inv_stretch, unsigned *__restrict__ marked) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    marked[b] = 0;
     float bt[30];
     load_beta(beta, T, times[b], bt);
     const double m = iwarp_min_stretch(bt, vol);
     inv_stretch[b] = m > 1e-3 ? (float)(1.0 / m) * 1.000001f : __builtin_inff();
 }
+
+struct IwarpScale {
+    float k[3], hk[3];   // (S-1)/S and S/(2 (S-1)) per axis (1 and 1/2 along a pinned z)
+};
 
 // One thread per lattice point: pre-image estimate, its cell, the box if it is larger; todo[g] = 1 where the box would
 // be too large.
@@ -108,15 +113,24 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
                                                                  const int *__restrict__ frame_ids, Volume vol,
                                                                  const float *__restrict__ beta, int T,
                                                                  const int *__restrict__ times,
-                                                                 const float *__restrict__ inv_stretch, float *__restrict__ out,
-                                                                 long ldo, unsigned char *__restrict__ todo) {
+                                                                 const float *__restrict__ inv_stretch, IwarpScale sc,
+                                                                 float *__restrict__ out, long ldo,
+                                                                 unsigned char *__restrict__ todo,
+                                                                 unsigned *__restrict__ marked) {
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= vol.P) return;
     unsigned char *flag = todo + (long)b * vol.P + g;
+    // marked[b] counts the marked points of frame b (one atomic per wave that marks any): the exhaustive kernel leaves
+    // a frame without marks after one scalar load
+    auto mark = [&]() {
+        *flag = 1;
+        const unsigned long long mm = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm)) atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm));
+    };
     const float inv_m = inv_stretch[b];
     if (!(inv_m < 1e3f)) {
-        *flag = 1;
+        mark();
         return;
     }
     const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
@@ -128,8 +142,7 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
     constexpr int ND = HASZ ? 3 : 2;
     // s(v) for a continuous v: q S/(S-1) (dNMF.py:81-83); k = (S-1)/S.  (Any rounding here only moves the estimate v:
     // what is left of g - s(v) is measured below and enters the radius.)
-    const float k[3] = {vol.sx1 / (float)vol.X, vol.sy1 / (float)vol.Y, HASZ ? vol.sz1 / (float)vol.Z : 1.0f};
-    const float hk[3] = {0.5f * (float)vol.X / vol.sx1, 0.5f * (float)vol.Y / vol.sy1, HASZ ? 0.5f * (float)vol.Z / vol.sz1 : 0.5f};
+    const float k[3] = {sc.k[0], sc.k[1], sc.k[2]}, hk[3] = {sc.hk[0], sc.hk[1], sc.hk[2]};
     const float gf[3] = {(float)gx, (float)gy, (float)gz};
     float v[3] = {gf[0] * k[0], gf[1] * k[1], HASZ ? gf[2] * k[2] : 0.0f};
     float res[3] = {0.0f, 0.0f, 0.0f};   // g - s(v)
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
         for (int d = 0; d < ND; ++d) res[d] = gf[d] - poly_a<HASZ>(b2, d, mo) * hk[d];
     };
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 2; ++it) {
         residual();
 #pragma unroll
         for (int d = 0; d < ND; ++d) v[d] += res[d] * k[d];
@@ -167,15 +180,16 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
         const long idx = ((long)x * vol.Y + yy) * vol.Z + z;
         if (d < best || (d == best && idx < arg)) best = d, arg = idx;   // ties: the lowest voxel index, as in the full search
     };
-    for (int x = c0[0]; x <= c1[0]; ++x)
-        for (int yy = c0[1]; yy <= c1[1]; ++yy)
-            for (int z = c0[2]; z <= c1[2]; ++z) candidate(x, yy, z);
+    // (an axis of one voxel names its only candidate twice; the second comparison changes nothing)
+#pragma unroll
+    for (int i = 0; i < (HASZ ? 8 : 4); ++i)
+        candidate((i & (HASZ ? 4 : 2)) ? c1[0] : c0[0], (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1], (HASZ && (i & 1)) ? c1[2] : c0[2]);
     // fp32 rounding of the positions (lattice and continuous evaluation): a few units in the last place at magnitudes
     // up to the volume size; the radius itself is evaluated in fp32, rounded generously upwards
     const float eps = 1e-4f + 1e-5f * (float)max(vol.X, max(vol.Y, vol.Z));
     const float r = ((sqrtf((float)best) + rho) * 1.00001f + 3.0f * eps) * inv_m + 1e-3f;
     if (!(r < (float)IW_RMAX)) {   // also NaN
-        *flag = 1;
+        mark();
         return;
     }
     int lo[3], hi[3];
@@ -199,9 +213,11 @@ __global__ __launch_bounds__(256) void image_iwarp_full_kernel(const float *__re
                                                                const int *__restrict__ frame_ids, Volume vol,
                                                                const float *__restrict__ beta, int T,
                                                                const int *__restrict__ times, float *__restrict__ out,
-                                                               long ldo, const unsigned char *__restrict__ todo) {
+                                                               long ldo, const unsigned char *__restrict__ todo,
+                                                               const unsigned *__restrict__ marked) {
     __shared__ float sx[IW_TILE], sy[IW_TILE], sz[IW_TILE];
     const int b = blockIdx.y;
+    if (marked && marked[b] == 0) return;   // block-uniform
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // lattice point served by this thread
     const bool mine = g < vol.P && todo[(long)b * vol.P + g];
     if (!__syncthreads_or(mine)) return;                         // nothing marked in this block
@@ -245,12 +261,17 @@ __global__ void count_flags_kernel(const unsigned char *__restrict__ todo, long 
 
 extern "C" {
 
-// one flag byte per lattice point and frame, then one float per frame
+__global__ void sum_marked_kernel(const unsigned *__restrict__ marked, int B, unsigned long long *__restrict__ count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && marked[b]) atomicAdd(count, (unsigned long long)marked[b]);
+}
+
+// one flag byte per lattice point and frame, then one float and one counter per frame
 static size_t iwarp_flag_bytes(int X, int Y, int Z, int B) { return ((size_t)X * Y * Z * B + 7) / 8 * 8; }
 
 size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B) {
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
-    return iwarp_flag_bytes(X, Y, Z, B) + sizeof(float) * (size_t)B;
+    return iwarp_flag_bytes(X, Y, Z, B) + (sizeof(float) + sizeof(unsigned)) * (size_t)B;
 }
 
 int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta, int T,
@@ -267,25 +288,37 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
     hipStream_t st = (hipStream_t)stream;
     unsigned char *todo = static_cast<unsigned char *>(workspace);
     const dim3 grid((unsigned)((vol.P + 255) / 256), (unsigned)B);
+    float *stretch = reinterpret_cast<float *>(todo + iwarp_flag_bytes(X, Y, Z, B));
+    unsigned *marked = reinterpret_cast<unsigned *>(stretch + B);
     if (exhaustive) {
+        marked = nullptr;
         hipError_t e = hipMemsetAsync(todo, 1, (size_t)vol.P * B, st);
         DNMF_REQUIRE(e == hipSuccess, (int)e, "dnmf_image_iwarp: hipMemsetAsync: %s", hipGetErrorString(e));
     } else {
-        float *stretch = reinterpret_cast<float *>(todo + iwarp_flag_bytes(X, Y, Z, B));
-        hipLaunchKernelGGL(iwarp_stretch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, beta, T, times, B, vol, stretch);
+        hipLaunchKernelGGL(iwarp_stretch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, beta, T, times, B, vol, stretch,
+                           marked);
+        IwarpScale sc;
+        const int S[3] = {X, Y, Z};
+        for (int d = 0; d < 3; ++d) {
+            const bool pinned = d == 2 && Z == 1;
+            sc.k[d] = pinned ? 1.0f : (float)(S[d] - 1) / (float)S[d];
+            sc.hk[d] = pinned ? 0.5f : 0.5f * (float)S[d] / (float)(S[d] - 1);   // an axis of one voxel: inf, and every point of
+        }                                                                       // the volume goes to the exhaustive search
         if (Z > 1)
             hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
-                               times, stretch, out, ldo, todo);
+                               times, stretch, sc, out, ldo, todo, marked);
         else
             hipLaunchKernelGGL(image_iwarp_window_kernel<false>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
-                               times, stretch, out, ldo, todo);
+                               times, stretch, sc, out, ldo, todo, marked);
     }
-    if (fallback_count) {
+    if (fallback_count && marked) {
+        hipLaunchKernelGGL(sum_marked_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, marked, B, fallback_count);
+    } else if (fallback_count) {
         const long n = vol.P * B;
         hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, todo, n, fallback_count);
     }
     hipLaunchKernelGGL(image_iwarp_full_kernel, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times, out, ldo,
-                       todo);
+                       todo, marked);
     return check_launch("dnmf_image_iwarp");
 }
 

@@ -680,16 +680,30 @@ __global__ __launch_bounds__(256) void lists_transpose_kernel(const float *__res
     for (int i = ty; i < 32; i += 8) {
         const int k = k0 + i;
         const long pp = p0 + tx;
-        if (k < K && pp < P) {
-            const float v = tile[tx][i];
-            int x, y, z;
+        const bool in = k < K && pp < P;
+        const float v = in ? tile[tx][i] : 0.0f;
+        int x = 0, y = 0, z = 0;
+        if (in) {
             voxel_xyz(pp, vol, x, y, z);
             At[(long)k * hl.Pp + (long)(x + HALO) * hl.rowf + (long)(y + HALO) * vol.Z + z] = v;
-            if (v != 0.0f) {
-                atomicMin(&bbox[k * 6 + 0], x), atomicMax(&bbox[k * 6 + 1], x);
-                atomicMin(&bbox[k * 6 + 2], y), atomicMax(&bbox[k * 6 + 3], y);
-                atomicMin(&bbox[k * 6 + 4], z), atomicMax(&bbox[k * 6 + 5], z);
+        }
+        // the box grows by what the 32 lanes that hold neuron k found, one set of atomics per half wave with a non-zero
+        // (one per non-zero voxel kept this kernel at 2.9 ms per call at 512x512, K=100: 76 GB/s)
+        const bool nz = v != 0.0f;
+        const unsigned long long any = __ballot(nz);
+        if (any == 0) continue;   // wave-uniform
+        int lo[3] = {nz ? x : 0x7fffffff, nz ? y : 0x7fffffff, nz ? z : 0x7fffffff};
+        int hi[3] = {nz ? x : -1, nz ? y : -1, nz ? z : -1};
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = min(lo[d], __shfl_xor(lo[d], off, 32));
+                hi[d] = max(hi[d], __shfl_xor(hi[d], off, 32));
             }
+        if (tx == 0 && hi[0] >= 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) atomicMin(&bbox[k * 6 + 2 * d], lo[d]), atomicMax(&bbox[k * 6 + 2 * d + 1], hi[d]);
         }
     }
 }
