@@ -178,7 +178,8 @@ class HostVideo(torch.utils.data.Dataset):
 def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spatial=False, loader="resident"):
     """Build the workload (synthetic video resident in HBM, model, loaders) and time `steps` sweeps after `warmup`.
     loader = "resident": the fit reads the rows where they lie; "dataloader": a stock torch DataLoader over a host
-    copy of the video (demo.py:33-35), every sweep crosses PCIe twice.  Returns a dict of measurements."""
+    copy of the video behind a plain Dataset (demo.py:33-35), every sweep crosses PCIe twice; "dataset": a stock
+    DataLoader over the library's SimulatedVideoDataset holding that host copy.  Returns a dict of measurements."""
     from dnmf_amd import ops
     from dnmf_amd.Demix import dNMF as M
     from dnmf_amd.WUtils import Simulator
@@ -205,7 +206,14 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
         train = M.ResidentLoader(frames, sz, bs, shuffle=True, generator=gen, t0=rank * T_loc, T_total=T_total)
         test = M.ResidentLoader(frames, sz, bs, shuffle=False)
     else:
-        host = HostVideo(frames.cpu(), sz)
+        if loader == "dataset":
+            # the library's own dataset class around a host video, as demo.py builds it (its constructor would run the CPU
+            # simulator: hours at this size): a stock DataLoader over it is served from dataset.device_frames()
+            host = M.SimulatedVideoDataset.__new__(M.SimulatedVideoDataset)
+            host.video = frames.cpu().view(frames.shape[0], *sz).permute(1, 2, 3, 0)
+            host.positions, host.traces, host._sz = positions, None, list(sz)
+        else:
+            host = HostVideo(frames.cpu(), sz)
         del frames
         frames = None
         train = torch.utils.data.DataLoader(host, batch_size=bs, shuffle=True, generator=torch.Generator().manual_seed(1234))
@@ -421,6 +429,13 @@ def main():
             dl[name] = short_line(r4, 2)
             del r4
             torch.cuda.empty_cache()
+        r5 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, loader="dataset")
+        dl["simulated_video_dataset_512x512x4000_K100"] = dict(
+            short_line(r5, 5), note="the same stock DataLoaders over the library's SimulatedVideoDataset (host video, as in "
+                                    "demo.py): frames come from dataset.device_frames(), only the loaders' index batches "
+                                    "are drawn")
+        del r5
+        torch.cuda.empty_cache()
         extras["stock_dataloader"] = dict(dl, note="torch.utils.data.DataLoader(batch 4, shuffle, num_workers=0) over a host "
                                                    "copy of the video, as demo.py:33-35; every sweep serves the video twice "
                                                    "from the host (update_motion, update_footprints)")

@@ -399,7 +399,13 @@ class DeformableNMF:
             return loader.frames_2d(), loader.order_tensor()
         staged = self._stage_epoch(loader) if self.stream_loader else None
         if staged is not None:
-            return staged[0], torch.tensor([t for b in staged[1] for t in b], dtype=torch.int32, device=device)
+            order = torch.tensor([t for b in staged[1] for t in b], dtype=torch.int32)
+            frames = staged[0]
+            if staged[2]:   # the dataset's device frames, row t = frame t: in the loader's order
+                n = order.numel()
+                if n != frames.shape[0] or not bool((order == torch.arange(n, dtype=torch.int32)).all()):
+                    frames = frames.index_select(0, order.to(device, torch.int64))
+            return frames, order.to(device)
         fr, idx = [], []
         for data in loader:
             fr.append(data[0].to(device, torch.float32).reshape(data[0].shape[0], -1))
@@ -658,14 +664,16 @@ class DeformableNMF:
                 if staged is None:      # unknown length or too large to stage: batch by batch from the host
                     self._motion_epoch_from_host(dataloader, optimizer, *recon())
                     continue
-                frames, batch_times = staged
+                frames, batch_times, by_frame = staged
                 plan = sharding.plan_from_batches(batch_times, fp.T)
                 norms = [len(b) for b in batch_times]
-                # row of the staging buffer that holds frame t
-                flat = torch.tensor([t for b in batch_times for t in b], dtype=torch.int64)
-                rows = torch.zeros(fp.T, dtype=torch.int32)
-                rows[flat] = torch.arange(flat.numel(), dtype=torch.int32)
-                rows = rows.to(device)
+                rows = None     # frame t in row t (a dataset's own device frames)
+                if not by_frame:
+                    # row of the staging buffer that holds frame t
+                    flat = torch.tensor([t for b in batch_times for t in b], dtype=torch.int64)
+                    rows = torch.zeros(fp.T, dtype=torch.int32)
+                    rows[flat] = torch.arange(flat.numel(), dtype=torch.int32)
+                    rows = rows.to(device)
                 if plan is None:        # a frame served twice in one epoch: the steps as they come
                     plan = sharding.EpochPlan(len(batch_times), None, None, None, [torch.tensor(b, dtype=torch.int64)
                                                                                    for b in batch_times])
@@ -725,6 +733,9 @@ class DeformableNMF:
         asynchronously), and the buffer is kept between calls."""
         n = self._loader_frames(loader)
         row = sum(f.P for f, _ in self._channels())
+        res = self._resident_batches(loader, row)
+        if res is not None:
+            return res[0], res[1], True
         if n is None or n == 0 or 4 * n * row > STAGE_LIMIT:
             return None
         if self._stage_buf is None or self._stage_buf.shape[0] < n or self._stage_buf.shape[1] != row:
@@ -745,7 +756,35 @@ class DeformableNMF:
             buf[at:at + B].copy_(src, non_blocking=src.is_pinned() if hasattr(src, "is_pinned") else False)
             batch_times.append(idx)
             at += B
-        return buf[:at], batch_times
+        return buf[:at], batch_times, False
+
+    @staticmethod
+    def _resident_batches(loader, row):
+        """``(frames, index batches)`` of one pass over a stock single-process ``DataLoader`` whose dataset keeps its
+        frames on the GPU (``dataset.device_frames()``: row t = frame t), without fetching a single sample: the
+        loader's iterator is created as for an ordinary pass -- it draws the seeds an ordinary pass draws, so shuffled
+        orders are the ones the reference loop would see -- and only its index batches are pulled.  None when the
+        loader is anything else."""
+        from torch.utils.data import DataLoader
+        from torch.utils.data._utils.collate import default_collate
+        from torch.utils.data.dataloader import _BaseDataLoaderIter
+        if type(loader) is not DataLoader or loader.num_workers != 0 or loader.batch_sampler is None \
+                or loader.collate_fn is not default_collate or not hasattr(_BaseDataLoaderIter, "_next_index"):
+            return None
+        get = getattr(loader.dataset, "device_frames", None)
+        if get is None:
+            return None
+        frames = get()
+        if frames.dim() != 2 or frames.shape[1] != row:
+            return None
+        it = iter(loader)
+        batches = []
+        while True:
+            try:
+                batches.append([int(i) for i in it._next_index()])
+            except StopIteration:
+                break
+        return frames, batches
 
     def _fusable(self, optimizer):
         """True when ``optimizer`` is exactly the reference demo's: torch.optim.Adam([fp.beta]) without
@@ -1019,6 +1058,21 @@ class SimulatedVideoDataset(Dataset):
         frames = self.video.permute(3, 0, 1, 2).reshape(self.video.shape[3], -1)
         frames = frames.to(device).clamp_(min=0)
         return ResidentLoader(frames, self._sz, batch_size, shuffle=shuffle, generator=generator)
+
+    def device_frames(self):
+        """(T, P) fp32 rows on the GPU, row t = what ``self[t][0]`` returns (clamped at 0).  The fit steps take the
+        frames of a stock ``DataLoader`` over this dataset from here instead of fetching and collating them one by one
+        on the host (~80 us per 512x512 frame: 150 times the GPU work of a sweep); the stored video is clamped in place
+        as a pass of ``__getitem__`` calls over all frames would leave it.  The copy is renewed when the stored
+        video has been written to since."""
+        v = self.video
+        cached = getattr(self, "_device_frames", None)
+        if cached is not None and cached[0] is v and cached[1] == v._version:
+            return cached[2]
+        v.clamp_(min=0)
+        frames = v.permute(3, 0, 1, 2).reshape(v.shape[3], -1).to(device, torch.float32).contiguous()
+        self._device_frames = (v, v._version, frames)
+        return frames
 
     def __len__(self):
         return self.video.shape[3]

@@ -478,6 +478,66 @@ def test_stock_dataloader_is_staged_and_matches_the_resident_path(M, O, monkeypa
     assert not torch.equal(c.fp.beta, a.fp.beta)
 
 
+def test_stock_dataloader_over_the_simulated_dataset_fetches_no_sample(M, O, monkeypatch):
+    """demo.py:26-38 as it stands: SimulatedVideoDataset + stock DataLoaders.  The fit takes the frames from
+    ``dataset.device_frames()`` and draws only the loaders' index batches: no ``__getitem__`` call, the shuffled order
+    (global RNG, no generator, as in the demo) is the one an ordinary pass over the loader draws, and beta, C equal the
+    host-staged path's bit for bit; the stored video ends clamped like after a pass of ``__getitem__`` calls."""
+    rng = np.random.RandomState(9)
+    sz, K, T, bs = [24, 20, 2], 4, 14, 4
+    pos = rng.rand(K, 3) * np.array(sz)
+    video = torch.from_numpy((rng.rand(*sz, T) - 0.1).astype(np.float32))   # some negative values: the clamp matters
+    C0 = rng.rand(K, T).astype(np.float32)
+
+    def dataset():
+        ds = M.SimulatedVideoDataset.__new__(M.SimulatedVideoDataset)   # the constructor would run the simulator
+        ds.video, ds.positions, ds.traces, ds._sz = video.clone(), None, None, list(sz)
+        return ds
+
+    def model():
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+        dn.verbose = False
+        dn.C = dev(C0)
+        return dn, torch.optim.Adam([dn.fp.beta], lr=1e-3)
+
+    def run(ds, count):
+        torch.manual_seed(77)   # the demo's loaders shuffle from the global generator
+        train = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=True, num_workers=0)
+        test = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=False, num_workers=0)
+        dn, opt = model()
+        for _ in range(2):
+            dn.update_motion(train, opt, gamma=1, epochs=2)
+            dn.update_footprints(test, bs, sz, gamma_c=0, iter_c=5, return_dense=False)
+        return dn, float(torch.rand(1))   # where the global generator stands afterwards
+
+    served = []
+    fast = dataset()
+    monkeypatch.setattr(M.SimulatedVideoDataset, "__getitem__", lambda self, i: served.append(i) or (self.video[..., i], i))
+    a, rng_a = run(fast, True)
+    assert served == []
+    assert float(fast.video.min()) == 0.0 and float(video.min()) < 0.0
+    monkeypatch.undo()
+
+    class Plain(torch.utils.data.Dataset):   # the same frames behind a dataset without device_frames: host staging
+        def __init__(self, v):
+            self.video = v
+
+        def __len__(self):
+            return self.video.shape[3]
+
+        def __getitem__(self, idx):
+            sample = self.video[:, :, :, idx]
+            sample[sample < 0] = 0
+            return sample, idx
+
+    b, rng_b = run(Plain(video.clone()), False)
+    assert torch.equal(a.fp.beta, b.fp.beta) and torch.equal(a.C, b.C)
+    assert rng_a == rng_b
+    # a write to the stored video renews the device copy
+    fast.video[..., 3] += 1.0
+    assert torch.equal(fast.device_frames()[3].cpu(), fast.video[..., 3].reshape(-1))
+
+
 @pytest.mark.parametrize("sz", [[1, 40, 3], [9, 1, 1], [600, 3, 1]])
 def test_static_update_temporal_takes_A_t_as_it_is(M, O, sz):
     """The static update_temporal (reference Demix/dNMF.py:139-149) contracts the A_t it is handed without re-sampling
