@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     p.tile_region[id] = reg;
 }
 
-template <int NTAP, int NW, int FAST, bool F32OFF>
+// LONGPASS = false: the tiles with at most LISTS_NG neurons, into fresh slot tables; true: the other tiles, ADDED to the
+// tables of the first pass (a second launch on the same stream).  Two kernels because the compiler allocates registers
+// for the union of all paths of one: with the long-list code inside, the short-list loop -- 95 % of the tiles -- spilled.
+template <int NTAP, int NW, int FAST, bool F32OFF, bool LONGPASS>
 __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gram_lists_kernel(ListParams p) {
     extern __shared__ float s_tab[];
     constexpr bool HASZ = NTAP == 8;
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     const int q_end = min(q_begin + p.chunk_len, p.ntiles);
     const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
     unsigned long long n_eval = 0, n_pair = 0;  // wave-uniform
+    bool any_tile = false;                      // wave-uniform
 #ifdef DNMF_K3N_STAMPS
     // diagnostic build only (tools/k3n_stamps.py): wave cycles per section of the tile loop into counters[2..8], then
     // the number of non-empty tiles, of long-list tiles and of flushed runs
@@ -339,6 +343,12 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
               my_reg = rg.x < 0 ? -1 : (rg.x << 16 | rg.y);
           }
       }
+      if (LONGPASS) {   // nothing for this pass among these 64 tiles?
+          int myn = 0;
+#pragma unroll
+          for (int wd = 0; wd < NW; ++wd) myn += __builtin_popcount(my_lo[wd]) + __builtin_popcount(my_hi[wd]);
+          if (__ballot(myn > LISTS_NG) == 0) continue;
+      }
       const int q1 = min(q0 + 64, q_end);
       for (int q = q0; q < q1; ++q) {
         const int jl = q - q0;
@@ -352,7 +362,8 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             n += __builtin_popcountll(msk[wd]);
             same = same && msk[wd] == prev[wd];
         }
-        if (n == 0) continue;
+        if (n == 0 || (n > LISTS_NG) != LONGPASS) continue;
+        any_tile = true;
         DNMF_STAMP(0)   // tile bookkeeping
 #ifdef DNMF_K3N_STAMPS
         st_acc[7] += 1, st_acc[8] += n > LISTS_NG, st_acc[9] += (!same || n > LISTS_NG) && run_n != 0;   // tiles, long lists, flushes
@@ -377,7 +388,8 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             const int rg = __builtin_amdgcn_readlane(my_reg, jl);
             reg_r0 = rg < 0 ? -1 : rg >> 16, reg_c0 = rg & 0xffff;
         }
-        const bool staged = !HASZ && reg_r0 >= 0 && n <= LISTS_NG;   // long lists keep the direct gathers (and their offsets)
+        // lists of more than two groups keep the direct gathers (and their offsets)
+        const bool staged = !HASZ && reg_r0 >= 0 && n <= 2 * LISTS_NG;
         // byte offset of volume voxel (0,0) inside a staged region, and of the region inside a footprint image
         const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
         const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         };
 
         n_eval += n, n_pair += n * (n + 1) / 2;
-        if (n <= LISTS_NG) {
+        if constexpr (!LONGPASS) {
             // the usual case: the whole list in registers; sums join the pending run (same list) or start one
             unsigned long long rem[NW];
 #pragma unroll
@@ -569,9 +581,78 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #endif
             DNMF_STAMP(4)   // taps from LDS (or direct gathers), per-lane sums
             continue;
+        } else {
+        if (staged) {
+            // Five to eight neurons on a staged tile: two groups A (four) and B through the same staging slots.  A's
+            // values stay in registers while its own sums are reduced like a finished run; then B's regions replace
+            // A's in LDS and every B neuron is summed against A, the frame and the B neurons before it.  (With direct
+            // gathers, every neuron of B evaluated twice and a table lookup in front of every group of sums these
+            // tiles -- 4.8 % of all at 512x512, K=100 -- took 17.6 % of the kernel's time.)
+            unsigned long long rem[NW];
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
+            int kA[LISTS_NG], kB[LISTS_NG];
+            take_ids(rem, kA);
+            take_ids(rem, kB);
+            const int nB = n - LISTS_NG;
+            float aA[LISTS_NG][LISTS_VPL], aB[LISTS_NG][LISTS_VPL];
+#pragma unroll
+            for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
+                f32x4 piece[2][2];
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) stage_load(kA[i], piece[i - i0]);
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+            }
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i) eval_staged(i, aA[i]);
+            {
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) {
+                    acc_r[i] = dot4(aA[i], yv, 0.0f);
+#pragma unroll
+                    for (int j = i; j < LISTS_NG; ++j, ++e) acc_p[e] = dot4(aA[i], aA[j], 0.0f);
+                    run_k[i] = kA[i];
+                }
+                run_n = LISTS_NG;
+                flush();
+            }
+#pragma unroll
+            for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
+                if (i0 >= nB) break;   // wave-uniform
+                f32x4 piece[2][2];
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) stage_load(max(kB[i], 0), piece[i - i0]);   // past the list: neuron 0, unused
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+            }
+#pragma unroll
+            for (int j = 0; j < LISTS_NG; ++j) {
+                if (j >= nB) break;   // wave-uniform
+                eval_staged(j, aB[j]);
+                int sc[LISTS_NG], sb[LISTS_NG];
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) sc[i] = pair_slot_of(kA[i], kB[j]);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) sb[i] = pair_slot_of(kB[i], kB[j]);
+                float tc[LISTS_NG], tb[LISTS_NG];
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) tc[i] = wave_sum_last(dot4(aA[i], aB[j], 0.0f));
+#pragma unroll
+                for (int i = 0; i <= j; ++i) tb[i] = wave_sum_last(dot4(aB[i], aB[j], 0.0f));
+                const float tr = wave_sum_last(dot4(aB[j], yv, 0.0f));
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) add_slot(sc[i], tc[i]);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) add_slot(sb[i], tb[i]);
+                add_slot(kB[j], tr);
+            }
+            DNMF_STAMP(6)   // a long-list tile, after its coordinates
+            continue;
         }
-        // long lists: groups of LISTS_NG neurons, every group against itself and against every later group; reduced
-        // and added tile by tile
+        // longer lists, 3-D volumes, tiles without a region: groups of LISTS_NG neurons with direct gathers, every group
+        // against itself and against every later group; reduced and added tile by tile
         unsigned long long rem1[NW];
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) rem1[wd] = msk[wd];
@@ -619,6 +700,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             }
         }
         DNMF_STAMP(6)   // a long-list tile, after its coordinates
+        }
       }
     }
     flush();
@@ -627,7 +709,11 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float *out = p.slab + ((long)b * p.nchunks + chunk) * p.nslot;
-    for (int i = lane; i < p.nslot; i += 64) out[i] = tab[i];
+    if (!LONGPASS) {
+        for (int i = lane; i < p.nslot; i += 64) out[i] = tab[i];
+    } else if (any_tile) {
+        for (int i = lane; i < p.nslot; i += 64) out[i] += tab[i];
+    }
     if (p.counters && lane == 0) {
         atomicAdd(&p.counters[0], n_eval);
         atomicAdd(&p.counters[1], n_pair);
@@ -771,16 +857,22 @@ static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len)
 
 static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
 
+template <int NTAP, int NW, int FAST, bool F32OFF>
+static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, false>), dim3(nwg), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, true>), dim3(nwg), dim3(256), lds, st, p);
+}
+
 template <int NTAP, int NW>
 static void launch_lists_t(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
     const long nthreads = (long)p.B * p.ntiles;
     hipLaunchKernelGGL((lists_tilemask_kernel<NW>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
     if (p.vol.fastdiv && p.hl.f32off)
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1, true>), dim3(nwg), dim3(256), lds, st, p);
+        launch_lists_passes<NTAP, NW, 1, true>(p, nwg, lds, st);
     else if (p.vol.fastdiv)
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 1, false>), dim3(nwg), dim3(256), lds, st, p);
+        launch_lists_passes<NTAP, NW, 1, false>(p, nwg, lds, st);
     else
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, 0, false>), dim3(nwg), dim3(256), lds, st, p);
+        launch_lists_passes<NTAP, NW, 0, false>(p, nwg, lds, st);
 }
 
 }  // namespace dnmf
