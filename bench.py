@@ -341,9 +341,10 @@ def main():
             # once (they stay in L2 / MALL across frames), G and r once
             abytes = 4.0 * P * T_loc + 4.0 * P * K + 4.0 * T_loc * (K * K + K)
             n_eval, n_pair = (float(v) / len(k3n) for v in res["lists_counters"][:2])
-            roof = {"kernel": f"warp_gram_lists_kernel<{ntap},{1 if K <= 64 else 2 if K <= 128 else 4},1,true> (K3n: per "
+            roof = {"kernel": f"warp_gram_lists_kernel<{ntap},{1 if K <= 64 else 2 if K <= 128 else 4},1,true,*> (K3n: per "
                               "256-voxel tile only the neurons whose non-zero box the tile's taps can reach; vector ALU, no "
-                              "MFMA) + lists_tilemask_kernel (the tiles' neuron lists), one API call",
+                              "MFMA; two launches: tiles with up to four neurons, then the others) + lists_tilemask_kernel "
+                              "(the tiles' neuron lists), one API call",
                     "bound": "hbm", "achieved": abytes / k3_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": abytes / k3_avg / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(key + "_lists"),
                     "launch_ms": 1e3 * k3_avg, "launches": len(k3n), "bytes_per_launch": abytes,
