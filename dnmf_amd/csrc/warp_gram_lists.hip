@@ -21,17 +21,17 @@
 //     k_lo - 1 <= l_hi and l_lo - 1 <= k_hi: a static pattern, independent of the warp (both footprints move
 //     under the same map).  Pairs outside the pattern are never accumulated and come out as 0.
 //
-// Data flow.  Lane = voxel (16 lanes along y: the neuron-major footprint copy At is read in coalesced 64-byte
-// runs), four voxels per lane along x; tiles are walked along x, so a lane's (y,z) and the monomials without x
-// change only at the end of a tile row.  At is in the halo layout of common.hpp:
+// Data flow.  Lane = voxel: 32 lanes along y for Z == 1 (a wave reads whole 128-byte lines of the frame; 16 for 3-D
+// volumes), four voxels per lane along x; tiles (8 x 32 x 1, 8 x 16 x 2 or 4 x 16 x 4 voxels) are walked along x, so a
+// lane's (y,z) and the monomials without x change only at the end of a tile row.  At is in the halo layout of common.hpp:
 // a tap outside the volume reads a zero, no masks or clamps along x and y.  Per listed neuron the warped values a_k of
 // the lane's voxels are NTAP FMAs on NTAP gathered taps.  Gathered straight from global memory those are 2 x NTAP/2
 // eight-byte loads per voxel with addresses that differ from lane to lane: ~16 cycles of a CU's texture path per
 // wave-instruction whatever its width (tools/gather_probe.hip), eight per neuron and tile, which kept that path 96 %
-// busy and set the kernel's time.  For Z == 1 the taps of a tile lie in a region of 20 rows x 24 floats of the footprint
+// busy and set the kernel's time.  For Z == 1 the taps of a tile lie in a region of 12 rows x 40 floats of the footprint
 // image (lists_tilemask_kernel: the tile's tap box, first column aligned to 16 bytes): the wave copies that region of
 // each listed neuron into LDS with two sixteen-byte loads per lane and gathers from LDS (2.5 cycles per instruction);
-// tiles whose taps do not fit (a warp that scales a tile by more than ~15 %) and 3-D volumes keep the direct gathers.
+// tiles whose taps do not fit (a warp that scales a tile by more than ~10 %) and 3-D volumes keep the direct gathers.
 // Then r_k += a_k.y and G_kl += a_k.a_l for the listed
 // l >= k as per-lane partial sums.  While consecutive tiles have the same list the partial sums stay in registers;
 // when the list changes: a fixed DPP tree over the 64 lanes and one LDS add by the last lane into the wave's private
@@ -46,6 +46,9 @@ namespace dnmf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DNMF_K3N_NT
+#define DNMF_K3N_NT 0   // frame values by non-temporal loads
+#endif
 #ifndef DNMF_K3N_WAVES
 #define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
 #endif
@@ -56,11 +59,11 @@ constexpr int LISTS_VPL = 1 << LISTS_LGV;
 constexpr int LISTS_MAXW = 4;    // 64-neuron words of a tile's list: K <= 256
 constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items per launch
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x 3800 words of LDS per workgroup
-// Staged gathers (Z == 1): the taps of a 16 x 16 tile lie in a region of RR rows x RC floats of a footprint image; a wave
+// Staged gathers (Z == 1): the taps of an 8 x 32 tile lie in a region of RR rows x RC floats of a footprint image; a wave
 // copies that region of each listed neuron into LDS with sixteen-byte loads and gathers from there (see the kernel).
-constexpr int LISTS_RR = 20, LISTS_RC = 24;                 // 17 tap rows / columns + alignment of the first column + slack
+constexpr int LISTS_RR = 12, LISTS_RC = 40;                 // 9 tap rows + slack; 33 tap columns + alignment of the first + slack
 constexpr int LISTS_REGION = LISTS_RR * LISTS_RC;            // floats per neuron: 1,920 bytes, 120 sixteen-byte pieces
-static_assert(LISTS_RC == 24 && LISTS_REGION / 4 <= 128, "the piece arithmetic of stage_load assumes six pieces per row");
+static_assert(LISTS_RC % 4 == 0 && LISTS_REGION / 4 <= 128 && LISTS_REGION / 4 > 64, "stage_load moves two pieces per lane");
 
 struct ListParams {
     const float *At;       // (K, halo layout)
@@ -83,7 +86,9 @@ struct ListParams {
     int2 *tile_region;     // (B, ntiles): first halo row / first float of a halo row of the tile's tap region; x < 0: the
                            // taps do not fit LISTS_RR x LISTS_RC (or Z > 1): direct gathers
     int nchunks, chunk_len;
-    int lgx, lgz;  // tile = (LISTS_VPL << lgx) x 16 x (1 << lgz) voxels, lgx + lgz = 2
+    int lgx, lgy, lgz;  // tile = (LISTS_VPL << lgx) x (1 << lgy) x (1 << lgz) voxels, lgx + lgy + lgz = 6: 8 x 32 x 1 for
+                        // Z == 1 (a wave reads whole 128-byte lines of a frame: with 16 voxels along y every line was
+                        // fetched twice, by tiles 32 apart in the walk), 8 x 16 x 2, 4 x 16 x 4
     int ntx, nty, ntz, ntiles;     // tile q = (qy * ntz + qz) * ntx + qx: walked along x
     unsigned long long *counters;  // optional: [0] += (tile, neuron) evaluations, [1] += (tile, pair) sums
 };
@@ -150,9 +155,9 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     float bt[30];
     load_beta(p.beta, p.T, t, bt);
     const int qx = q % p.ntx, rest = q / p.ntx, qz = rest % p.ntz, qy = rest / p.ntz;
-    const int tx = LISTS_VPL << p.lgx, tz = 1 << p.lgz;
+    const int tx = LISTS_VPL << p.lgx, ty = 1 << p.lgy, tz = 1 << p.lgz;
     const int S[3] = {vol.X, vol.Y, vol.Z};
-    const int first[3] = {qx * tx, qy * 16, qz * tz}, size[3] = {tx, 16, tz};
+    const int first[3] = {qx * tx, qy * ty, qz * tz}, size[3] = {tx, ty, tz};
     float lo[3], hi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) lo[d] = (float)first[d], hi[d] = (float)min(first[d] + size[d] - 1, S[d] - 1);
@@ -221,12 +226,15 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     // this wave's LISTS_NG staging regions (NTAP == 4 only; 16-byte aligned: the tables before them are padded)
     char *stage_lds = reinterpret_cast<char *>(s_tab + (((size_t)4 * p.nslot + 3) & ~(size_t)3)) +
                       (size_t)wave * (LISTS_NG * LISTS_REGION * 4);
-    // piece e = lane + 64 j (j = 0, 1) of a region is row e / 6, floats 4 (e % 6) .. +3
-    const int piece_row = lane / (LISTS_RC / 4), piece_c4 = lane - piece_row * (LISTS_RC / 4);   // of piece `lane`
+    // piece e = lane + 64 j (j = 0, 1) of a region is row e / (RC/4), floats 4 (e % (RC/4)) .. +3
+    constexpr int PPR = LISTS_RC / 4;
+    const int piece_row[2] = {lane / PPR, (lane + 64) / PPR};
+    const int piece_c4[2] = {lane - piece_row[0] * PPR, lane + 64 - piece_row[1] * PPR};
     const int2 *__restrict__ regions = p.tile_region + (long)b * p.ntiles;
 
     const int lgx = p.lgx, lgz = p.lgz;
-    const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & 15, lx = lane >> (lgz + 4);
+    const int lgy = p.lgy;
+    const int lz = lane & ((1 << lgz) - 1), ly = (lane >> lgz) & ((1 << lgy) - 1), lx = lane >> (lgz + lgy);
     const int q_begin = chunk * p.chunk_len;
     const int q_end = min(q_begin + p.chunk_len, p.ntiles);
     const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
@@ -376,11 +384,11 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         const int qx = q % p.ntx, rest = q / p.ntx;
         if (rest != row_of_c) {
             const int qz = rest % p.ntz, qy = rest / p.ntz;
-            mono = monomials<HASZ>(0.0f, (float)((qy << 4) + ly), (float)((qz << lgz) + lz));
+            mono = monomials<HASZ>(0.0f, (float)((qy << lgy) + ly), (float)((qz << lgz) + lz));
             row_of_c = rest;
         }
         const int qz = rest % p.ntz, qy = rest / p.ntz;
-        const int y = (qy << 4) + ly, z = (qz << lgz) + lz;
+        const int y = (qy << lgy) + ly, z = (qz << lgz) + lz;
         const bool yz_in = y < vol.Y && z < vol.Z;
         // staged gathers for this tile?  (wave-uniform)
         int reg_r0 = -1, reg_c0 = 0;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         float yv[LISTS_VPL];
         const int xt = qx << (lgx + LISTS_LGV);  // first x of the tile
         const float x0f = (float)(xt + lx);
-        const bool full = xt + (LISTS_VPL << lgx) <= vol.X && (qy << 4) + 16 <= vol.Y && (qz << lgz) + (1 << lgz) <= vol.Z;
+        const bool full = xt + (LISTS_VPL << lgx) <= vol.X && (qy << lgy) + (1 << lgy) <= vol.Y && (qz << lgz) + (1 << lgz) <= vol.Z;
         // frame values: (scalar base + 32-bit lane offset) loads; the voxels of a lane are (1 << lgx) rows apart
         const unsigned yo0 = (unsigned)(((xt + lx) * vol.Y + min(y, vol.Y - 1)) * vol.Z + min(z, vol.Z - 1)) * 4u;
         const unsigned ystep = (unsigned)((vol.Y * vol.Z) << lgx) * 4u;
@@ -450,7 +458,8 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #ifdef DNMF_K3N_ABL_FRAME   // timing ablation: no frame loads
                 const float val = __builtin_bit_cast(float, yo);
 #else
-                const float val = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(yb) + yo);
+                const float *yp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(yb) + yo);
+                const float val = DNMF_K3N_NT ? __builtin_nontemporal_load(yp) : *yp;
 #endif
                 yv[v] = in ? val : 0.0f;
             }
@@ -486,9 +495,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane + reg_goff;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                // piece lane + 64: 64 = 10 rows + 4 pieces further on
-                const int c4 = piece_c4 + (j ? 4 : 0), row = piece_row + (j ? 10 : 0) + (c4 >= LISTS_RC / 4 ? 1 : 0);
-                unsigned o = (unsigned)(row * hl.row4 + (c4 >= LISTS_RC / 4 ? c4 - LISTS_RC / 4 : c4) * 16);
+                unsigned o = (unsigned)(piece_row[j] * hl.row4 + piece_c4[j] * 16);
                 asm("" : "+v"(o));
                 piece[j] = (j == 0 || lane + 64 < LISTS_REGION / 4) ? *reinterpret_cast<const f32x4 *>(Ak + o)
                                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -836,13 +843,14 @@ __global__ __launch_bounds__(256) void lists_pairs_kernel(const int *__restrict_
     }
 }
 
-static void lists_tile_shape(const Volume &vol, int &lgx, int &lgz, int &ntx, int &nty, int &ntz, int &ntiles) {
+static void lists_tile_shape(const Volume &vol, int &lgx, int &lgy, int &lgz, int &ntx, int &nty, int &ntz, int &ntiles) {
     lgz = vol.Z == 1 ? 0 : (vol.Z == 2 ? 1 : 2);
-    lgx = 2 - lgz;
-    const int tx = LISTS_VPL << lgx, tz = 1 << lgz;
+    lgy = vol.Z == 1 ? 5 : 4;
+    lgx = 6 - lgy - lgz;
+    const int tx = LISTS_VPL << lgx, ty = 1 << lgy, tz = 1 << lgz;
     ntx = (vol.X + tx - 1) / tx;
     ntz = (vol.Z + tz - 1) / tz;
-    nty = (vol.Y + 15) / 16;
+    nty = (vol.Y + ty - 1) / ty;
     ntiles = ntx * nty * ntz;
 }
 
@@ -916,8 +924,8 @@ static size_t lists_slab_bytes(int nslot, int B) {
 size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z, int B) {
     using namespace dnmf;
     if (nslot <= 0 || B <= 0 || K <= 0 || K > 64 * LISTS_MAXW || X <= 0 || Y <= 0 || Z <= 0) return 0;
-    int lgx, lgz, ntx, nty, ntz, ntiles;
-    lists_tile_shape(make_volume(X, Y, Z), lgx, lgz, ntx, nty, ntz, ntiles);
+    int lgx, lgy, lgz, ntx, nty, ntz, ntiles;
+    lists_tile_shape(make_volume(X, Y, Z), lgx, lgy, lgz, ntx, nty, ntz, ntiles);
     return lists_slab_bytes(nslot, B) + (size_t)B * ntiles * (lists_words(K) * sizeof(unsigned long long) + sizeof(int2));
 }
 
@@ -947,7 +955,7 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
     p.slab = static_cast<float *>(workspace);
     p.tile_masks = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + lists_slab_bytes(nslot, B));
     p.counters = counters;
-    lists_tile_shape(p.vol, p.lgx, p.lgz, p.ntx, p.nty, p.ntz, p.ntiles);
+    lists_tile_shape(p.vol, p.lgx, p.lgy, p.lgz, p.ntx, p.nty, p.ntz, p.ntiles);
     lists_choose_chunks(p.ntiles, B, p.nchunks, p.chunk_len);
     DNMF_REQUIRE(workspace_bytes >= dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B), DNMF_E_WORKSPACE,
                  "dnmf_warp_gram_rhs_lists: workspace %zu < %zu bytes", workspace_bytes,
@@ -979,8 +987,8 @@ int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B) {
     using namespace dnmf;
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
     const Volume vol = make_volume(X, Y, Z);
-    int lgx, lgz, ntx, nty, ntz, ntiles, nchunks, chunk_len;
-    lists_tile_shape(vol, lgx, lgz, ntx, nty, ntz, ntiles);
+    int lgx, lgy, lgz, ntx, nty, ntz, ntiles, nchunks, chunk_len;
+    lists_tile_shape(vol, lgx, lgy, lgz, ntx, nty, ntz, ntiles);
     lists_choose_chunks(ntiles, B, nchunks, chunk_len);
     return nchunks;
 }
