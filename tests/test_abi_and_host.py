@@ -143,6 +143,49 @@ def test_dataset_protocol_and_in_place_clamp():
     assert tuple(batch[0].shape) == (4, 16, 16, 2) and batch[1].tolist() == [0, 1, 2, 3]
 
 
+def test_index_batches_of_a_stock_dataloader_without_fetching_samples():
+    """``DeformableNMF._resident_batches``: for a dataset that hands over its frames (``device_frames()``) only the index
+    batches of a stock DataLoader are drawn -- the same batches, and the same draws from the global generator, as an
+    ordinary pass over the loader; other loaders are left alone."""
+    from dnmf_amd.Demix.dNMF import DeformableNMF
+
+    class Frames(torch.utils.data.Dataset):
+        fetched = 0
+
+        def __init__(self, n, row):
+            self.frames = torch.arange(n * row, dtype=torch.float32).reshape(n, row)
+
+        def device_frames(self):
+            return self.frames
+
+        def __len__(self):
+            return self.frames.shape[0]
+
+        def __getitem__(self, i):
+            Frames.fetched += 1
+            return self.frames[i], i
+
+    ds = Frames(11, 6)
+    for shuffle in (False, True):
+        torch.manual_seed(5)
+        ordinary = [idx.tolist() for _, idx in torch.utils.data.DataLoader(ds, batch_size=4, shuffle=shuffle)]
+        after_ordinary = float(torch.rand(1))
+        Frames.fetched = 0
+        torch.manual_seed(5)
+        frames, batches = DeformableNMF._resident_batches(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=shuffle), 6)
+        assert batches == ordinary and Frames.fetched == 0 and frames is ds.frames
+        assert float(torch.rand(1)) == after_ordinary
+    assert [len(b) for b in batches] == [4, 4, 3]
+    dropped = DeformableNMF._resident_batches(torch.utils.data.DataLoader(ds, batch_size=4, drop_last=True), 6)[1]
+    assert [len(b) for b in dropped] == [4, 4]
+    # not taken: a row length the model does not expect, a custom collate function, a dataset without device_frames
+    assert DeformableNMF._resident_batches(torch.utils.data.DataLoader(ds, batch_size=4), 7) is None
+    assert DeformableNMF._resident_batches(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=lambda b: b), 6) is None
+    plain = torch.utils.data.TensorDataset(ds.frames, torch.arange(11))
+    assert DeformableNMF._resident_batches(torch.utils.data.DataLoader(plain, batch_size=4), 6) is None
+    assert DeformableNMF._resident_batches([(ds.frames[:4], torch.arange(4))], 6) is None
+
+
 def test_neuropal_dataset_reads_mat_files(tmp_path):
     """The real-data loader of the reference (its data is not in the tree): round trip through scipy's .mat files."""
     from scipy.io import savemat
