@@ -3,10 +3,11 @@
 // whole padded image, so the border of S is rewritten (as the zeros the border of At holds) by every call.
 //
 // Same role as recon_image.hip (the reference's einsum of Demix/dNMF.py:58, taken before the warp because the
-// gather is linear).  A tile of 4 x 64 voxels (64 lanes along the contiguous axis, so a wave stores 256-byte runs)
-// needs only the neurons whose non-zero box meets it: a static list.  The wave keeps their footprint values for its
-// four voxels per lane in registers and sweeps a run of frames: per frame and lane 4 x (listed neurons) FMAs and
-// four stores -- the kernel is bound by writing S.
+// gather is linear).  A tile of 4 rows x 64 positions of the contiguous axis needs only the neurons whose non-zero box
+// meets it: a static list.  A lane owns four consecutive positions of one row (16 lanes per row), so the wave keeps the
+// footprint values of its voxels as one 16-byte register quad per neuron and sweeps a run of frames: per frame and lane
+// 4 x (listed neurons) FMAs and ONE 16-byte store (a wave writes four 256-byte runs with one instruction; four 4-byte
+// stores per lane reached 65 % of the HBM roof) -- the kernel is bound by writing S.
 //
 // Terms with an exact zero factor are the only ones dropped, so S equals the dense product up to the order of the
 // fp32 additions (ascending neuron index here).
@@ -14,6 +15,7 @@
 
 namespace dnmf {
 
+typedef float rl_f4 __attribute__((ext_vector_type(4)));
 constexpr int RL_NG = 8;  // neurons held in registers at a time
 
 template <int NW>
@@ -30,9 +32,10 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
     const int b1 = min(b0 + frames_per_wave, B);
     const int YZ = hl.rowf;                            // one padded row (a multiple of 32 floats)
     const int qu = tile % nu, qx = tile / nu;
-    const int u = 64 * qu + lane;                      // position in the padded (y,z) plane
-    const bool uin = u < YZ;
-    const int x0 = 4 * qx;                             // padded row
+    const int row = lane >> 4;                         // row of the tile this lane works in
+    const int u = 64 * qu + 4 * (lane & 15);           // its first position in the padded (y,z) plane (YZ is a multiple of 4)
+    const int x0 = 4 * qx;                             // first padded row of the tile
+    const bool in = u < YZ && x0 + row < hl.Xp;
     // box of the tile in volume coordinates
     const int ylo = (64 * qu) / vol.Z - HALO, yhi = min(64 * qu + 63, hl.Yp * vol.Z - 1) / vol.Z - HALO;
     const int xlo = x0 - HALO, xhi = min(x0 + 3, hl.Xp - 1) - HALO;
@@ -56,30 +59,24 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    float *__restrict__ out = S + (long)x0 * YZ + u;
+    const long voxel = (long)(x0 + row) * YZ + u;
+    float *__restrict__ out = S + voxel;
+    const rl_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (n == 0) {
         for (int b = b0; b < b1; ++b)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (uin && x0 + v < hl.Xp) out[(long)b * lds + (long)v * YZ] = 0.0f;
+            if (in) *reinterpret_cast<rl_f4 *>(out + (long)b * lds) = zero4;
         return;
     }
     for (int g = 0; g < n; g += RL_NG) {
         // footprint values of this group at the lane's voxels (0 beyond the list / outside the volume)
         const int mine = lst[min(g + (lane & 7), n - 1)];
         int ks[RL_NG];
-        float a[RL_NG][4];
+        rl_f4 a[RL_NG];
 #pragma unroll
         for (int i = 0; i < RL_NG; ++i) {
             ks[i] = g + i < n ? __builtin_amdgcn_readlane(mine, i) : -1;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) a[i][v] = 0.0f;
-            if (ks[i] >= 0) {
-                const float *__restrict__ Ak = At + (long)ks[i] * hl.Pp + (long)x0 * YZ + u;
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (uin && x0 + v < hl.Xp) a[i][v] = Ak[(long)v * YZ];
-            }
+            a[i] = zero4;
+            if (ks[i] >= 0 && in) a[i] = *reinterpret_cast<const rl_f4 *>(At + (long)ks[i] * hl.Pp + voxel);
         }
         // frames in runs of 64: lane j fetches the traces of frame bb + j, the run then reads them as scalars
         for (int bb = b0; bb < b1; bb += 64) {
@@ -90,22 +87,16 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
             for (int i = 0; i < RL_NG; ++i) cv[i] = ks[i] >= 0 ? C[(long)ks[i] * ldc + tcol] : 0.0f;
             const int nb = min(64, b1 - bb);
             for (int j = 0; j < nb; ++j) {
-                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                float *__restrict__ dst = out + (long)(bb + j) * lds;
-                if (g > 0) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (uin && x0 + v < hl.Xp) s[v] = dst[(long)v * YZ];
-                }
+                rl_f4 s = zero4;
+                rl_f4 *__restrict__ dst = reinterpret_cast<rl_f4 *>(out + (long)(bb + j) * lds);
+                if (g > 0 && in) s = *dst;
 #pragma unroll
                 for (int i = 0; i < RL_NG; ++i) {
                     const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[i]), j));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) s[v] = fmaf(a[i][v], c, s[v]);
                 }
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (uin && x0 + v < hl.Xp) dst[(long)v * YZ] = s[v];
+                if (in) *dst = s;
             }
         }
     }
@@ -125,6 +116,8 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
     const Volume vol = make_volume(X, Y, Z);
     const HaloLayout hl = make_halo_layout(X, Y, Z);
     DNMF_REQUIRE(lds >= hl.Pp, DNMF_E_SHAPE, "dnmf_recon_image_lists: lds=%ld < %ld floats of a halo-layout image", lds, hl.Pp);
+    DNMF_REQUIRE((lds & 3) == 0 && ((size_t)S & 15) == 0 && ((size_t)At & 15) == 0, DNMF_E_SHAPE,
+                 "dnmf_recon_image_lists: S, At must be 16-byte aligned and lds (%ld) a multiple of 4 floats", lds);
     const int nu = (hl.rowf + 63) / 64;
     const long ntile = (long)((hl.Xp + 3) / 4) * nu;
     DNMF_REQUIRE(ntile < (1L << 31), DNMF_E_UNSUPPORTED, "dnmf_recon_image_lists: %ld tiles", ntile);

@@ -187,7 +187,8 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
                              size_t workspace_bytes, unsigned long long *counters, dnmf_stream_t stream);
 
 /* Reconstruction image from the K3n layout: S (halo layout) as dnmf_recon_image, summing per tile of 4 x 64 voxels only the neurons
- * whose box meets the tile (static lists); bound by writing S.  K <= 256. */
+ * whose box meets the tile (static lists); bound by writing S.  K <= 256.  At and S 16-byte aligned, lds a multiple of 4
+ * floats (dnmf_halo_voxels is a multiple of 32). */
 int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
                            const int *times, int B, float *S, long lds, dnmf_stream_t stream);
 
