@@ -49,6 +49,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DNMF_K3N_NT
 #define DNMF_K3N_NT 0   // frame values by non-temporal loads
 #endif
+// Coordinates of a voxel's taps.  0 (the product build): the reference's fp32 sequence -- the ten-term FMA chain,
+// n = 2q/(S-1) - 1, u = ((n+1)/2)(S-1) -- which is what decides floor() at lattice coincidences and what K2, K1 and the
+// dense kernels evaluate.  1 (a measured option, -DDNMF_K3N_DIRECT=1): u_d = q_d(x, y, z) evaluated directly, as a
+// quadratic in x with coefficients the lane keeps per tile row: two FMAs per axis and voxel instead of ~20 instructions,
+// 109 registers instead of 128, 3.24 ms against 3.45 per 4000 frames at 512x512, K=100.  The interpolated footprint
+// value is a CONTINUOUS function of u, so G and r then differ from the faithful evaluation only by what ~1e-5 px of
+// coordinate noise make (the reference's own round trip through n loses that much near the middle of an axis): up to
+// 7e-6 of the largest entry on the sharp test footprints, inside the stated 2e-5 but three times what separates the
+// faithful K3n from the dense kernel -- not worth 3 % of a sweep.
+#ifndef DNMF_K3N_DIRECT
+#define DNMF_K3N_DIRECT 0
+#endif
 #ifndef DNMF_K3N_WAVES
 #define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
 #endif
@@ -330,6 +342,9 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     double_beta(bt, b2);
     Monomials<HASZ> mono = monomials<HASZ>(0.0f, 0.0f, 0.0f);
     int row_of_c = -1;  // the tile row (qy, qz) `mono` belongs to
+#if DNMF_K3N_DIRECT
+    float hc0[3] = {0.f, 0.f, 0.f}, hc1[3] = {0.f, 0.f, 0.f}, hc2[3] = {0.f, 0.f, 0.f};
+#endif
     unsigned long long prev[NW];
 #pragma unroll
     for (int wd = 0; wd < NW; ++wd) prev[wd] = 0;
@@ -385,6 +400,18 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         if (rest != row_of_c) {
             const int qz = rest % p.ntz, qy = rest / p.ntz;
             mono = monomials<HASZ>(0.0f, (float)((qy << lgy) + ly), (float)((qz << lgz) + lz));
+#if DNMF_K3N_DIRECT
+#pragma unroll
+            for (int d = 0; d < (HASZ ? 3 : 2); ++d) {   // q_d = hc0 + x (hc1 + x hc2) for this lane's (y, z)
+                hc2[d] = bt[12 + d];
+                hc1[d] = fmaf(bt[21 + d], mono.y, bt[3 + d]);
+                hc0[d] = fmaf(bt[15 + d], mono.yy, fmaf(bt[6 + d], mono.y, bt[d]));
+                if (HASZ) {
+                    hc1[d] = fmaf(bt[24 + d], mono.z, hc1[d]);
+                    hc0[d] = fmaf(bt[27 + d], mono.yz, fmaf(bt[18 + d], mono.zz, fmaf(bt[9 + d], mono.z, hc0[d])));
+                }
+            }
+#endif
             row_of_c = rest;
         }
         const int qz = rest % p.ntz, qy = rest / p.ntz;
@@ -418,21 +445,34 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #pragma unroll
             for (int v = 0; v < LISTS_VPL; ++v) {
                 const int x = xt + (v << lgx) + lx;
+                float fx, fy, wx[2], wy[2];
+#if DNMF_K3N_DIRECT
+                const float xf = x0f + (float)(v << lgx);
+                float ud[3];
+#pragma unroll
+                for (int d = 0; d < (HASZ ? 3 : 2); ++d) ud[d] = fmaf(xf, fmaf(xf, hc2[d], hc1[d]), hc0[d]);
+                axis_taps_halo(ud[0], hl.xhi, fx, wx[0], wx[1]);
+                axis_taps_halo(ud[1], hl.yhi, fy, wy[0], wy[1]);
+#else
                 Monomials<HASZ> m = mono;
                 m.x = x0f + (float)(v << lgx), m.xx = __fmul_rn(m.x, m.x), m.xy = __fmul_rn(m.x, m.y);
                 if (HASZ) m.xz = __fmul_rn(m.x, m.z);
-                float fx, fy, wx[2], wy[2];
                 axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 0, m), vol, 0), vol.hx1), hl.xhi, fx, wx[0],
                                wx[1]);
                 axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 1, m), vol, 1), vol.hy1), hl.yhi, fy, wy[0],
                                wy[1]);
+#endif
                 const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);
                 float wzm[2] = {1.0f, 0.0f};
                 unsigned zo[2] = {0u, 0u};
                 if (HASZ) {
                     int iz;
                     float wz[2];
+#if DNMF_K3N_DIRECT
+                    axis_weights(ud[2], iz, wz[0], wz[1]);
+#else
                     axis_weights(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1), iz, wz[0], wz[1]);
+#endif
 #pragma unroll
                     for (int dz = 0; dz < 2; ++dz) {
                         wzm[dz] = in_range(iz + dz, vol.Z) ? wz[dz] : 0.0f;
