@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line; it also carries
                 (configs[1] whole, a 400-frame subset of configs[2]): PCIe- and host-inclusive frames/s
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -46,6 +47,10 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # a sweep takes ~10 ms; the first few after an idle period run ~30 % slower (clock ramp), hence the defaults
+    # 20 + 5 sweeps: the fit stays where the demo's would be after as many (Adam's momentum moves every coefficient of
+    # every frame at every step, dNMF.py:191; after ~100 sweeps the warps have drifted by tens of voxels and the traces of
+    # neurons that lost their support grow without bound -- finite, but no longer the workload); `sweep_ms_on_stream`
+    # shows how even the timed sweeps were
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512, help="X = Y (Z = 1)")
@@ -239,11 +244,19 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
         if counters is not None:
             counters.zero_()
     fence()
+    # one event per sweep on the stream the kernels run on: the spread of the sweep times goes into the line
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    gc.collect()
+    gc.disable()   # no collector pauses between launches inside the timed region
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    sweep_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     timing, ops.TIMING = ops.TIMING, None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -268,13 +281,15 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     per_step = {name: 1e3 * sum(evs(name)) / steps for name in timing}
     return {"elapsed": elapsed, "evs": evs, "per_step_ms": per_step, "dn": dn, "frames": frames, "positions0": positions0,
             "sanity": sanity, "lr": lr,
+            "sweep_ms": {"min": round(sweep_ms[0], 3), "median": round(sweep_ms[len(sweep_ms) // 2], 3),
+                         "max": round(sweep_ms[-1], 3)},
             "lists_counters": lists_counters, "sparse_counters": sparse_counters, "T_total": T_total}
 
 
 def short_line(res, steps):
     """frames/s, ms per sweep and the per-kernel HIP-event times of a secondary measurement."""
     return {"value": res["T_total"] * steps / res["elapsed"], "unit": "frames/s", "steps": steps,
-            "ms_per_step": 1e3 * res["elapsed"] / steps, "fit_sanity": res["sanity"],
+            "ms_per_step": 1e3 * res["elapsed"] / steps, "sweep_ms_on_stream": res["sweep_ms"], "fit_sanity": res["sanity"],
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())}}
 
 
@@ -402,6 +417,8 @@ def main():
             "breakdown_ms_per_step": {"gram": 1e3 * sum(k3) / args.steps,
                                       "K2_motion_kernels": 1e3 * (sum(k2) + sum(evs("motion_grad_lists"))) / args.steps},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())},
+            # HIP events between the sweeps of the timed region (this rank): how even they were
+            "sweep_ms_on_stream": res["sweep_ms"],
             "fit_sanity": res["sanity"],
             "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key, ops.halo_voxels(sz)),
         }
