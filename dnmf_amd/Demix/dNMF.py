@@ -1103,6 +1103,14 @@ class NeuroPALVideoDataset(Dataset):
         self.positions[:, 2, :] /= 10
         self.names = pos_mat['neuron_names'][0]
 
+    def device_frames(self):
+        """(T, P) fp32 rows on the GPU, row t = what ``self[t][0]`` returns; see ``SimulatedVideoDataset.device_frames``.
+        The video is a numpy array without a write counter, so the copy is made anew at every call (a pass over the
+        100 frames the reference keeps)."""
+        np.maximum(self.video, 0, out=self.video)
+        T = self.video.shape[3]
+        return torch.from_numpy(np.ascontiguousarray(np.moveaxis(self.video, 3, 0)).reshape(T, -1)).to(device, torch.float32)
+
     def __len__(self):
         return self.video.shape[3]
 

@@ -538,6 +538,43 @@ def test_stock_dataloader_over_the_simulated_dataset_fetches_no_sample(M, O, mon
     assert torch.equal(fast.device_frames()[3].cpu(), fast.video[..., 3].reshape(-1))
 
 
+def test_recorded_video_dataset_hands_over_its_frames(M, tmp_path):
+    """NeuroPALVideoDataset behind stock DataLoaders: the fit takes ``device_frames()`` and gets the traces and warps of
+    the same frames served sample by sample (a dataset class without that method)."""
+    from scipy.io import savemat
+    rng = np.random.RandomState(3)
+    data = rng.rand(24, 20, 20, 9) - 0.05
+    pos = 1 + rng.rand(3, 3, 9) * np.array([24, 20, 20])[None, :, None]
+    savemat(tmp_path / "data.mat", {"data": data})
+    savemat(tmp_path / "traces_n.mat", {"positions": pos, "neuron_names": np.array([["a", "b", "c"]], dtype=object)})
+
+    class SampleBySample(torch.utils.data.Dataset):
+        def __init__(self, ds):
+            self.ds = ds
+
+        def __len__(self):
+            return len(self.ds)
+
+        def __getitem__(self, i):
+            return self.ds[i]
+
+    results = []
+    for wrap in (False, True):
+        ds = M.NeuroPALVideoDataset(str(tmp_path))
+        sz, T, K = list(ds.video.shape[:3]), len(ds), ds.positions.shape[0]
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=ds.positions[:, :, 0])
+        dn.verbose = False
+        dn.C = dev(np.linspace(0.2, 1.0, K * T, dtype=np.float32).reshape(K, T))
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-4)
+        served = SampleBySample(ds) if wrap else ds
+        dn.update_motion(torch.utils.data.DataLoader(served, batch_size=4, shuffle=True,
+                                                     generator=torch.Generator().manual_seed(2)), opt, gamma=1, epochs=2)
+        dn.update_footprints(torch.utils.data.DataLoader(served, batch_size=4), 4, sz, gamma_c=0, iter_c=6, return_dense=False)
+        results.append((dn.fp.beta.detach().clone(), dn.C.clone(), float(ds.video.min())))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    assert results[0][2] == 0.0 and results[1][2] == 0.0
+
+
 @pytest.mark.parametrize("sz", [[1, 40, 3], [9, 1, 1], [600, 3, 1]])
 def test_static_update_temporal_takes_A_t_as_it_is(M, O, sz):
     """The static update_temporal (reference Demix/dNMF.py:139-149) contracts the A_t it is handed without re-sampling
