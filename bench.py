@@ -30,6 +30,7 @@ import gc
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -288,6 +289,44 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
             "lists_counters": lists_counters, "sparse_counters": sparse_counters, "T_total": T_total}
 
 
+def sharded_footprint_update(dn, frames, sz, bs, iter_c, group, world, updates=2):
+    """N > 1 only, after the timed region: the one step of the path that exchanges data between ranks -- the live
+    footprint update (registration K7, K5 over the local frames, ONE all-reduce of the A1 | C_s buffer over RCCL, K6).
+    Every rank must end with the same footprints."""
+    import torch.distributed as dist
+    from dnmf_amd import ops
+    from dnmf_amd.Demix import dNMF as M
+    test = M.ResidentLoader(frames, sz, bs, shuffle=False)
+    P, K = dn.fp.P, dn.fp.K
+
+    def update():
+        dn.update_footprints(test, bs, sz, gamma_c=0, gamma_a=1.0, iter_c=iter_c, return_dense=False, live_spatial=True)
+
+    update()   # first use: buffers, the registered video
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    ops.TIMING = {}
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        update()
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    elapsed = time.perf_counter() - t0
+    timing, ops.TIMING = ops.TIMING, None
+    ar = [a.elapsed_time(b) for a, b in timing.get("allreduce", [])]
+    check = dn.fp.A.double().sum().reshape(1)
+    sums = [torch.zeros_like(check) for _ in range(world)]
+    dist.all_gather(sums, check, group=group)
+    nbytes = 4 * (P * K + K * K)
+    return {"what": "update_footprints(live_spatial=True) on every rank: K3n + K4, K7, K5, one all-reduce (sum) of A1 | C_s, K6",
+            "backend": "torch.distributed 'nccl' = RCCL" if dist.get_backend(group) == "nccl" else f"torch.distributed '{dist.get_backend(group)}'",
+            "ranks": world,
+            "ms_per_update_max_over_ranks": 1e3 * elapsed / updates,
+            "allreduce_ms_rank0": round(sum(ar) / max(1, len(ar)), 3), "allreduce_calls": len(ar), "allreduce_bytes": nbytes,
+            "allreduce_algbw_GBps": round(nbytes / (1e6 * max(1e-9, sum(ar) / max(1, len(ar)))), 1),
+            "footprints_identical_on_all_ranks": bool(all(float(v) == float(sums[0]) for v in sums))}
+
+
 def short_line(res, steps):
     """frames/s, ms per sweep and the per-kernel HIP-event times of a secondary measurement."""
     return {"value": res["T_total"] * steps / res["elapsed"], "unit": "frames/s", "steps": steps,
@@ -460,6 +499,33 @@ def main():
                                                    "copy of the video, as demo.py:33-35; every sweep serves the video twice "
                                                    "from the host (update_motion, update_footprints)")
         line["extras"] = extras
+    # N > 1: the sweep above shards without any collective; the path's one real exchange (the footprint update's
+    # all-reduce) is exercised here, outside the timed region, under a watchdog -- if any rank fails or the collective
+    # does not come back, rank 0 still prints the line (without this entry) and every rank leaves
+    if world > 1 and not args.no_extras and not args.with_spatial and Z == 1 and K <= 128:
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                line["extras"] = {"sharded_footprint_update": {"error": "no answer within 240 s"}}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(240.0, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            ex = sharded_footprint_update(dn, frames, sz, bs, args.iter_c, group, world)
+        except Exception as err:   # the other ranks are stuck in the collective: leave through the watchdog
+            print(f"[bench] rank {rank}: sharded_footprint_update failed: {err!r}", file=sys.stderr, flush=True)
+            time.sleep(300.0)
+            ex = None
+        finished.set()
+        timer.cancel()
+        if rank == 0 and ex is not None:
+            line["extras"] = {"sharded_footprint_update": ex}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -292,7 +292,11 @@ class DeformableNMF:
         # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
         # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
         self.group = None
-        self._comm = None  # ops.Communicator over self.group, built by spatial_step when the backend is RCCL
+        self._comm = None  # ops.Communicator over self.group, built by spatial_step when collective == "c1"
+        # the one collective of the path (spatial_step): 'torch' = torch.distributed.all_reduce on self.group (RCCL under the
+        # "nccl" backend); 'c1' = dnmf_allreduce_sum_f32 on the library's own communicator.  C1 has only ever run with one
+        # rank (one GPU per test box), so it is not the default
+        self.collective = "torch"
         self._spatial_buf = None   # A1 (P,K) and C_s (K,K) of spatial_step, one buffer = one all-reduce
         self._ws_mg = None
         # > 0: the fused motion epoch on compact footprints makes its reconstruction images this many frames at a time
@@ -373,12 +377,13 @@ class DeformableNMF:
                 A1[:, s0:s0 + 128] = part
             Cs.copy_((Cl.double() @ Cl.double().T).float())
         if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
-            if torch.distributed.get_backend(self.group) == "nccl":
-                # one process per GPU: the library's own RCCL communicator (C1), built on first use
+            if self.collective == "c1" and torch.distributed.get_backend(self.group) == "nccl":
+                # the library's own RCCL communicator (C1 of the C ABI: what a host without torch would call), built on
+                # first use
                 if self._comm is None:
                     self._comm = ops.Communicator(self.group)
                 self._comm.all_reduce_(buf)
-            else:  # ranks that share a card or run without one (gloo rehearsal): RCCL cannot span them
+            else:  # the caller's process group: RCCL when its backend is "nccl" (one process per GPU), gloo in rehearsals
                 with ops._timed("allreduce"):
                     torch.distributed.all_reduce(buf, group=self.group)
         A2 = fp.A.reshape(P, K).contiguous()

@@ -67,17 +67,20 @@ pos = torch.from_numpy(rng.rand(K, 3) * np.array(sz)).float()
 frames = torch.rand(T, sz[0] * sz[1] * sz[2]).cuda()
 C0 = torch.rand(K, T)
 
-def run(t0, t1, group):
+def run(t0, t1, group, collective="torch"):
     dn = M.DeformableNMF(torch.tensor(sz), K, t1 - t0, positions=pos)
-    dn.verbose, dn.group = False, group
+    dn.verbose, dn.group, dn.collective = False, group, collective
     dn.C = C0[:, t0:t1].cuda().contiguous()
     A = dn.spatial_step(frames[t0:t1], D=torch.rand(*sz, K, generator=torch.Generator().manual_seed(1)), gamma=0.3)
     return A.clone(), dn
 
 t0, t1 = sharding.shard_bounds(T, world, rank)
-A_s, dn = run(t0, t1, dist.group.WORLD)       # ONE dnmf_allreduce_sum_f32 (RCCL) of the packed A1 | C_s buffer
-assert dn._comm is not None and dn._comm.nranks == world
 A_f, _ = run(0, T, None)
+A_t, dn_t = run(t0, t1, dist.group.WORLD)      # ONE torch.distributed all-reduce (RCCL) of the packed A1 | C_s buffer
+assert dn_t._comm is None
+assert torch.allclose(A_t, A_f, rtol=2e-5, atol=1e-30), float(((A_t - A_f).abs() / (A_f.abs() + 1e-30)).max())
+A_s, dn = run(t0, t1, dist.group.WORLD, "c1")  # ONE dnmf_allreduce_sum_f32 on the library's own RCCL communicator
+assert dn._comm is not None and dn._comm.nranks == world
 assert torch.allclose(A_s, A_f, rtol=2e-5, atol=1e-30), float(((A_s - A_f).abs() / (A_f.abs() + 1e-30)).max())
 dn._comm.close()
 dist.barrier()
@@ -87,8 +90,8 @@ print("rank", rank, "ok")
 
 
 def test_two_ranks_rccl(tmp_path):
-    """The same spatial update over the library's own RCCL communicator, one GPU per rank: runs where two GPUs are
-    visible (the driver's multi-GPU node), skips on the one-GPU test box."""
+    """The same spatial update over RCCL, one GPU per rank -- through the caller's process group (the default) and
+    through the library's own communicator (C1): runs where two GPUs are visible, skips on the one-GPU test box."""
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     script = tmp_path / "worker_nccl.py"
