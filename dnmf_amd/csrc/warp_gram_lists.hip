@@ -208,11 +208,16 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     p.tile_region[id] = reg;
 }
 
-// LONGPASS = false: the tiles with at most LISTS_NG neurons, into fresh slot tables; true: the other tiles, ADDED to the
-// tables of the first pass (a second launch on the same stream).  Two kernels because the compiler allocates registers
-// for the union of all paths of one: with the long-list code inside, the short-list loop -- 95 % of the tiles -- spilled.
-template <int NTAP, int NW, int FAST, bool F32OFF, bool LONGPASS>
+// PASS 1: the tiles with at most LISTS_NG neurons, into fresh slot tables; PASS 2: the other tiles, ADDED to the tables
+// of pass 1 (a second launch on the same stream).  Two kernels because the compiler allocates registers for the union
+// of all paths of one: with the staged long-list code inside, the short-list loop spilled.  Where few tiles have long
+// lists (the reference's density: 5 %) the pair is faster than one kernel; where many do (footprints twice as dense:
+// 45 %) the second pass, which is bound by its chains of memory round trips with nothing to hide them behind, costs more
+// than it saves -- PASS 0 is the one-kernel form (every tile, long lists by direct gathers) for that case; the host picks
+// by the size of the pattern (lists_passes).
+template <int NTAP, int NW, int FAST, bool F32OFF, int PASS>
 __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gram_lists_kernel(ListParams p) {
+    constexpr bool LONGPASS = PASS == 2;
     extern __shared__ float s_tab[];
     constexpr bool HASZ = NTAP == 8;
     constexpr int NPAIR = LISTS_NG * (LISTS_NG + 1) / 2;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             n += __builtin_popcountll(msk[wd]);
             same = same && msk[wd] == prev[wd];
         }
-        if (n == 0 || (n > LISTS_NG) != LONGPASS) continue;
+        if (n == 0 || (PASS == 1 && n > LISTS_NG) || (PASS == 2 && n <= LISTS_NG)) continue;
         any_tile = true;
         DNMF_STAMP(0)   // tile bookkeeping
 #ifdef DNMF_K3N_STAMPS
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             reg_r0 = rg < 0 ? -1 : rg >> 16, reg_c0 = rg & 0xffff;
         }
         // lists of more than two groups keep the direct gathers (and their offsets)
-        const bool staged = !HASZ && reg_r0 >= 0 && n <= 2 * LISTS_NG;
+        const bool staged = !HASZ && reg_r0 >= 0 && n <= (PASS == 2 ? 2 : 1) * LISTS_NG;
         // byte offset of volume voxel (0,0) inside a staged region, and of the region inside a footprint image
         const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
         const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         };
 
         n_eval += n, n_pair += n * (n + 1) / 2;
-        if constexpr (!LONGPASS) {
+        if (PASS != 2 && n <= LISTS_NG) {
             // the usual case: the whole list in registers; sums join the pending run (same list) or start one
             unsigned long long rem[NW];
 #pragma unroll
@@ -628,8 +633,9 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #endif
             DNMF_STAMP(4)   // taps from LDS (or direct gathers), per-lane sums
             continue;
-        } else {
-        if (staged) {
+        }
+        if constexpr (PASS != 1) {
+        if (PASS == 2 && staged) {
             // Five to eight neurons on a staged tile: two groups A (four) and B through the same staging slots.  A's
             // values stay in registers while its own sums are reduced like a finished run; then B's regions replace
             // A's in LDS and every B neuron is summed against A, the frame and the B neurons before it.  (With direct
@@ -905,10 +911,23 @@ static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len)
 
 static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
 
+// One kernel or two?  The pattern tells how dense the footprints lie: (nslot - K - 1) / K pairs (k, l >= k) per neuron --
+// 3.6 at the reference's density (512x512, K=100: 5 % of the tiles list more than four neurons), 5.9 with twice the
+// density (256x256, K=50: 45 %).  And a second launch has its fixed cost per wave (table, slab): it pays only when a wave
+// has a long run of tiles (512x512: 205 tiles per wave at 4000 frames, 25 at 400, where one kernel takes 0.54 ms and
+// two take 0.89).
+static int lists_passes(int nslot, int K, int chunk_len) {
+    return (2 * (nslot - K - 1) > 9 * K || chunk_len < 100) ? 1 : 2;
+}
+
 template <int NTAP, int NW, int FAST, bool F32OFF>
 static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, false>), dim3(nwg), dim3(256), lds, st, p);
-    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, true>), dim3(nwg), dim3(256), lds, st, p);
+    if (lists_passes(p.nslot, p.K, p.chunk_len) == 1) {
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 0>), dim3(nwg), dim3(256), lds, st, p);
+        return;
+    }
+    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
 }
 
 template <int NTAP, int NW>
