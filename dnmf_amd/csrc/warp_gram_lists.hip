@@ -210,11 +210,9 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
 
 // PASS 1: the tiles with at most LISTS_NG neurons, into fresh slot tables; PASS 2: the other tiles, ADDED to the tables
 // of pass 1 (a second launch on the same stream).  Two kernels because the compiler allocates registers for the union
-// of all paths of one: with the staged long-list code inside, the short-list loop spilled.  Where few tiles have long
-// lists (the reference's density: 5 %) the pair is faster than one kernel; where many do (footprints twice as dense:
-// 45 %) the second pass, which is bound by its chains of memory round trips with nothing to hide them behind, costs more
-// than it saves -- PASS 0 is the one-kernel form (every tile, long lists by direct gathers) for that case; the host picks
-// by the size of the pattern (lists_passes).
+// of all paths of one: with the staged long-list code inside, the short-list loop spilled.  PASS 0 is the one-kernel
+// form (every tile, long lists by direct gathers) for launches whose waves have only a short run of tiles each, where the
+// second launch costs more than it saves; the host picks (lists_passes).
 template <int NTAP, int NW, int FAST, bool F32OFF, int PASS>
 __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gram_lists_kernel(ListParams p) {
     constexpr bool LONGPASS = PASS == 2;
@@ -911,18 +909,16 @@ static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len)
 
 static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
 
-// One kernel or two?  The pattern tells how dense the footprints lie: (nslot - K - 1) / K pairs (k, l >= k) per neuron --
-// 3.6 at the reference's density (512x512, K=100: 5 % of the tiles list more than four neurons), 5.9 with twice the
-// density (256x256, K=50: 45 %).  And a second launch has its fixed cost per wave (table, slab): it pays only when a wave
-// has a long run of tiles (512x512: 205 tiles per wave at 4000 frames, 25 at 400, where one kernel takes 0.54 ms and
-// two take 0.89).
-static int lists_passes(int nslot, int K, int chunk_len) {
-    return (2 * (nslot - K - 1) > 9 * K || chunk_len < 100) ? 1 : 2;
-}
+// One kernel or two?  A second launch has its fixed cost per wave (table, slab, the scan for its tiles): it pays when a
+// wave has a long run of tiles -- 512x512, K=100: 205 tiles per wave at 4000 frames (3.6 ms against 3.7), 25 at 400
+// frames (0.89 ms against 0.51 in one kernel); 256x256x1000, K=50: 16 tiles per wave, 0.92 against 0.58.  The density
+// of the footprints does not decide it: 512x512x4000 with K=200 (45 % of the tiles list more than four neurons) takes
+// 9.1 ms in two launches and 12.2 in one.
+static int lists_passes(int chunk_len) { return chunk_len < 100 ? 1 : 2; }
 
 template <int NTAP, int NW, int FAST, bool F32OFF>
 static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
-    if (lists_passes(p.nslot, p.K, p.chunk_len) == 1) {
+    if (lists_passes(p.chunk_len) == 1) {
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 0>), dim3(nwg), dim3(256), lds, st, p);
         return;
     }
