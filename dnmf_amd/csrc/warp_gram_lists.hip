@@ -93,11 +93,12 @@ struct ListParams {
     const float *frames;
     long ldf;
     const int *frame_ids;
-    float *slab;  // (B, nchunks, nslot)
+    float *slab;  // (B, tables, nslot): table c of a frame from chunk c; with two launches table nchunks + c from the second
     unsigned long long *tile_masks;  // (B, ntiles, NW): the neuron list of every tile of every frame
     int2 *tile_region;     // (B, ntiles): first halo row / first float of a halo row of the tile's tap region; x < 0: the
                            // taps do not fit LISTS_RR x LISTS_RC (or Z > 1): direct gathers
     int nchunks, chunk_len;
+    int tables;            // nchunks, or 2 nchunks when the long-list tiles go in a launch of their own
     int lgx, lgy, lgz;  // tile = (LISTS_VPL << lgx) x (1 << lgy) x (1 << lgz) voxels, lgx + lgy + lgz = 6: 8 x 32 x 1 for
                         // Z == 1 (a wave reads whole 128-byte lines of a frame: with 16 voxels along y every line was
                         // fetched twice, by tiles 32 apart in the walk), 8 x 16 x 2, 4 x 16 x 4
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     p.tile_region[id] = reg;
 }
 
-// PASS 1: the tiles with at most LISTS_NG neurons, into fresh slot tables; PASS 2: the other tiles, ADDED to the tables
-// of pass 1 (a second launch on the same stream).  Two kernels because the compiler allocates registers for the union
+// PASS 1: the tiles with at most LISTS_NG neurons; PASS 2: the other tiles, into tables of their own (the consumers sum
+// a frame's tables in order), launched on a side stream so that the two run side by side: pass 2 alone is a chain of
+// memory round trips per tile with nothing to hide them behind.  Two kernels because the compiler allocates registers for the union
 // of all paths of one: with the staged long-list code inside, the short-list loop spilled.  PASS 0 is the one-kernel
 // form (every tile, long lists by direct gathers) for launches whose waves have only a short run of tiles each, where the
 // second launch costs more than it saves; the host picks (lists_passes).
@@ -759,12 +761,8 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float *out = p.slab + ((long)b * p.nchunks + chunk) * p.nslot;
-    if (!LONGPASS) {
-        for (int i = lane; i < p.nslot; i += 64) out[i] = tab[i];
-    } else if (any_tile) {
-        for (int i = lane; i < p.nslot; i += 64) out[i] += tab[i];
-    }
+    float *out = p.slab + ((long)b * p.tables + (LONGPASS ? p.nchunks : 0) + chunk) * p.nslot;
+    for (int i = lane; i < p.nslot; i += 64) out[i] = tab[i];
     if (p.counters && lane == 0) {
         atomicAdd(&p.counters[0], n_eval);
         atomicAdd(&p.counters[1], n_pair);
@@ -916,14 +914,47 @@ static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
 // 9.1 ms in two launches and 12.2 in one.
 static int lists_passes(int chunk_len) { return chunk_len < 100 ? 1 : 2; }
 
+// The stream the second pass runs on and the two events of its fork / join, one set per device, made on first use and
+// kept (the only state this file holds).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream &side_stream() {
+    static SideStream per_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    SideStream &ss = per_device[dev];
+    if (!ss.stream) {
+        hipStream_t s = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess)
+            ss.stream = s, ss.fork = a, ss.join = b;
+    }
+    return ss;
+}
+
 template <int NTAP, int NW, int FAST, bool F32OFF>
 static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
-    if (lists_passes(p.chunk_len) == 1) {
+    if (p.tables == p.nchunks) {
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 0>), dim3(nwg), dim3(256), lds, st, p);
         return;
     }
-    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
-    hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
+    // fork: the second pass on the side stream behind the lists, join before anything that follows on `st`
+    SideStream &ss = side_stream();
+    if (ss.stream) {
+        hipEventRecord(ss.fork, st);
+        hipStreamWaitEvent(ss.stream, ss.fork, 0);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, ss.stream, p);
+        hipEventRecord(ss.join, ss.stream);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
+        hipStreamWaitEvent(st, ss.join, 0);
+    } else {   // no side stream to be had: one after the other
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
+    }
 }
 
 template <int NTAP, int NW>
@@ -973,7 +1004,7 @@ static size_t lists_slab_bytes(int nslot, int B) {
     long want = (dnmf::LISTS_ITEMS + B - 1) / B;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
-    return ((size_t)B * (size_t)want * (size_t)nslot * sizeof(float) + 255) / 256 * 256;
+    return ((size_t)B * (size_t)(2 * want) * (size_t)nslot * sizeof(float) + 255) / 256 * 256;   // up to two tables per chunk
 }
 
 size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z, int B) {
@@ -1012,6 +1043,7 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
     p.counters = counters;
     lists_tile_shape(p.vol, p.lgx, p.lgy, p.lgz, p.ntx, p.nty, p.ntz, p.ntiles);
     lists_choose_chunks(p.ntiles, B, p.nchunks, p.chunk_len);
+    p.tables = p.nchunks * lists_passes(p.chunk_len);
     DNMF_REQUIRE(workspace_bytes >= dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B), DNMF_E_WORKSPACE,
                  "dnmf_warp_gram_rhs_lists: workspace %zu < %zu bytes", workspace_bytes,
                  dnmf_warp_gram_rhs_lists_workspace(nslot, K, X, Y, Z, B));
@@ -1033,7 +1065,7 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
         else launch_lists_t<4, 4>(p, nwg, lds, st);
     }
     if (G)
-        hipLaunchKernelGGL(gram_lists_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, p.slab, p.nchunks, nslot,
+        hipLaunchKernelGGL(gram_lists_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, p.slab, p.tables, nslot,
                            pair_slot, K, G, r);
     return check_launch("dnmf_warp_gram_rhs_lists");
 }
@@ -1045,7 +1077,7 @@ int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B) {
     int lgx, lgy, lgz, ntx, nty, ntz, ntiles, nchunks, chunk_len;
     lists_tile_shape(vol, lgx, lgy, lgz, ntx, nty, ntz, ntiles);
     lists_choose_chunks(ntiles, B, nchunks, chunk_len);
-    return nchunks;
+    return nchunks * lists_passes(chunk_len);
 }
 
 }  // extern "C"
