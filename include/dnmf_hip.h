@@ -175,7 +175,10 @@ int dnmf_warp_gram_rhs_sparse_lt(const float *Aps, int Ks, int K, const int *ord
  *   the slot tables are left at the start of the workspace for dnmf_mu_temporal_slots);
  *   nslot <= 3800 (DNMF_E_UNSUPPORTED beyond: the footprints overlap too much, use K3 / K3s);
  *   workspace: dnmf_warp_gram_rhs_lists_workspace(nslot,K,X,Y,Z,B) bytes (slot tables, then the tile lists);
- *   counters: NULL, or 2 x uint64 INCREMENTED by the (tile, neuron) evaluations and the (tile, pair) sums done. */
+ *   counters: NULL, or 2 x uint64 INCREMENTED by the (tile, neuron) evaluations and the (tile, pair) sums done.
+ *   Long videos: the tiles with more than four neurons are evaluated by a second launch on a side stream the library
+ *   keeps (forked from `stream` behind the lists, joined back to it before the call's last kernel): ordering on
+ *   `stream` is as if everything ran there. */
 size_t dnmf_lists_axis_masks_bytes(int X, int Y, int Z, int K);
 int dnmf_pack_footprints_lists(const float *A, int X, int Y, int Z, int K, float *At, int *bbox, int *pair_slot,
                                int *nslot, void *axis_masks, dnmf_stream_t stream);
