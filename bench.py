@@ -257,7 +257,9 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    sweep_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    sweep_each = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    slowest = max(range(steps), key=lambda i: sweep_each[i])
+    sweep_ms = sorted(sweep_each)
     timing, ops.TIMING = ops.TIMING, None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -285,7 +287,7 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     return {"elapsed": elapsed, "evs": evs, "per_step_ms": per_step, "dn": dn, "frames": frames, "positions0": positions0,
             "sanity": sanity, "lr": lr,
             "sweep_ms": {"min": round(sweep_ms[0], 3), "median": round(sweep_ms[len(sweep_ms) // 2], 3),
-                         "max": round(sweep_ms[-1], 3)},
+                         "max": round(sweep_ms[-1], 3), "slowest_is_sweep": slowest},
             "lists_counters": lists_counters, "sparse_counters": sparse_counters, "T_total": T_total}
 
 
