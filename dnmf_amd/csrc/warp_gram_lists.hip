@@ -38,6 +38,7 @@
 // table of pattern slots.  LDS operations of one wave retire in order, so the sum is deterministic.  The table
 // goes to a slab per (frame, chunk); the finish kernel adds the chunks in order and scatters the slots into dense
 // G (K,K), r (K).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -912,7 +913,14 @@ static int lists_words(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : 4); }
 // frames (0.89 ms against 0.51 in one kernel); 256x256x1000, K=50: 16 tiles per wave, 0.92 against 0.58.  The density
 // of the footprints does not decide it: 512x512x4000 with K=200 (45 % of the tiles list more than four neurons) takes
 // 9.1 ms in two launches and 12.2 in one.
-static int lists_passes(int chunk_len) { return chunk_len < 100 ? 1 : 2; }
+// DNMF_LISTS_PASSES=1|2 in the environment overrides the choice (the parity tests run both forms on small problems).
+static int lists_passes(int chunk_len) {
+    if (const char *e = getenv("DNMF_LISTS_PASSES")) {
+        if (e[0] == '1' && e[1] == 0) return 1;
+        if (e[0] == '2' && e[1] == 0) return 2;
+    }
+    return chunk_len < 100 ? 1 : 2;
+}
 
 // The stream the second pass runs on and the two events of its fork / join, one set per device, made on first use and
 // kept (the only state this file holds).

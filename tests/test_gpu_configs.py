@@ -72,10 +72,13 @@ class Calls:
 
 
 @pytest.mark.parametrize("label", ["lr1e-5_ordered", "lr1e-3_ordered", "lr1e-3_shuffled"])
-def test_bench_path_vs_fixture_G9(M, O, monkeypatch, label):
+@pytest.mark.parametrize("passes", ["auto", "2"])
+def test_bench_path_vs_fixture_G9(M, O, monkeypatch, label, passes):
     """Fixture G9 (one outer iteration of the reference's demo loop, produced by the reference itself) through the
     bench's path: resident loader, fused Adam epoch (one K2 launch per group of equal mini-batch size on the cached
     reconstruction images), neuron-list Gram kernel; same tolerances as the list-loader test of the same fixture."""
+    if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
     g = golden("G9_loop")
     lr, epochs, shuffled, bs = g[label + "_cfg"]
     bs = int(bs)
@@ -143,13 +146,16 @@ def test_bench_path_vs_oracle_config1(M, O, monkeypatch):
     assert np.all(got[~calm].max(1) > 10)
 
 
-def test_bench_path_slot_tables_vs_oracle(M, O, monkeypatch):
+@pytest.mark.parametrize("passes", ["auto", "2"])
+def test_bench_path_slot_tables_vs_oracle(M, O, monkeypatch, passes):
     """The whole chain of a bench sweep including K4 on the slot tables of K3n (taken when the pattern of G has at
     most 32 columns per row and K >= 8): compact footprints well inside a 2-D volume, warps that start off the
     lattice, one sweep = update_motion(epochs=1, shuffled mini-batches) + update_footprints(iter_c=50, gamma_c=0),
     against the CPU oracle on the same batches.  Off-lattice start and well-conditioned Gram matrices (every
     footprint inside the volume), so the tolerances are the tight ones: beta 2e-3 of the largest displacement,
     C rtol 1e-4."""
+    if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
     rng = np.random.RandomState(11)
     sz, K, T, bs = [96, 80, 1], 12, 8, 4
     pos = np.stack([12 + rng.rand(K) * 72, 12 + rng.rand(K) * 56, np.zeros(K)], 1).astype(np.float32)

@@ -436,11 +436,14 @@ def test_full_size_properties(M):
     assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
 
 
-def test_full_size_neuron_list_path(M):
+@pytest.mark.parametrize("passes", ["auto", "2"])
+def test_full_size_neuron_list_path(M, passes, monkeypatch):
     """The bench's default path at its geometry (512x512, K=100): K3n, the list reconstruction and K4 on the slot
     tables, through the same size-independent properties -- identity warp => A^T A; integer shifts => Gram of the
     shifted footprints; S = A.C against a float64 product; the fused update_footprints equals the two-step one bit
     for bit; a full sweep through the model leaves finite, non-negative traces."""
+    if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
     from dnmf_amd import ops
     torch.manual_seed(0)
     sz, K, T = [512, 512, 1], 100, 8
@@ -612,12 +615,15 @@ def test_demo_loop_recovers_traces(M, capsys):
 @pytest.mark.parametrize("sz,K,T,sigma", [([64, 48, 1], 30, 5, 1.0), ([70, 50, 1], 100, 4, 0.8), ([40, 33, 2], 20, 3, 1.2),
                                           ([24, 40, 5], 40, 3, 0.9), ([33, 47, 1], 50, 4, 3.0), ([96, 80, 1], 200, 3, 0.7),
                                           ([16, 16, 1], 3, 2, 3.0), ([48, 40, 3], 70, 2, 3.0), ([66000, 6, 1], 12, 2, 1.5)])
-def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma):
+@pytest.mark.parametrize("passes", ["auto", "2"])
+def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma, passes, monkeypatch):
     """K3n against K3 on the same inputs: narrow footprints (short lists, empty tiles), the reference's sigma = 3 on
     small volumes (every neuron listed everywhere: groups of 4 and the cross-group path), 2-D and 3-D tiles, ragged
     volume edges, K up to 200 (four list words), warps that push part of the volume outside, an axis longer than
     65536 (IEEE division instead of the shortcut).  Sums agree to fp32
     summation order; the pattern of exact zeros of G is the dense kernel's; two launches agree bitwise."""
+    if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
     from dnmf_amd import ops
     rng = np.random.RandomState(K + sz[0])
     pos = rng.rand(K, 3) * np.array(sz)
@@ -704,11 +710,14 @@ def test_recon_image_from_lists(M, O, sz, K, sigma):
     assert border_is_zero(S[:, :Pp], sz)                        # the border of every image: rewritten as zeros
 
 
-def test_neuron_list_gram_under_strong_warps(M, O):
+@pytest.mark.parametrize("passes", ["auto", "2"])
+def test_neuron_list_gram_under_strong_warps(M, O, passes, monkeypatch):
     """K3n's tile lists come from the taps its voxels actually have, whatever the warp does.  Forty frames whose warps
     range from mild to violent (shifts up to the volume size, shear and scale of order one, quadratic terms that bend
     the volume by tens of voxels, one frame with non-finite coefficients): the result must still be the dense
     kernel's."""
+    if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
     from dnmf_amd import ops
     rng = np.random.RandomState(123)
     sz, K, T = [112, 96, 1], 60, 40
