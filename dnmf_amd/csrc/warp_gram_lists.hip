@@ -897,8 +897,14 @@ static void lists_tile_shape(const Volume &vol, int &lgx, int &lgy, int &lgz, in
     ntiles = ntx * nty * ntz;
 }
 
+// DNMF_LISTS_CHUNKS=n in the environment (1 .. 64) asks for n chunks per frame instead: the parity tests use it to give a
+// wave of a small problem the long runs of tiles (and of equal lists) it has at the bench size.
 static void lists_choose_chunks(int ntiles, int B, int &nchunks, int &chunk_len) {
     long want = (LISTS_ITEMS + B - 1) / B;  // wave-sized work items: several rounds of four waves per SIMD
+    if (const char *e = getenv("DNMF_LISTS_CHUNKS")) {
+        const long n = strtol(e, nullptr, 10);
+        if (n >= 1 && n <= 64 && n <= want) want = n;   // never more tables than the workspace was sized for
+    }
     if (want < 1) want = 1;
     if (want > 64) want = 64;
     if (want > ntiles) want = ntiles;

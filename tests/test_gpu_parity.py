@@ -615,7 +615,7 @@ def test_demo_loop_recovers_traces(M, capsys):
 @pytest.mark.parametrize("sz,K,T,sigma", [([64, 48, 1], 30, 5, 1.0), ([70, 50, 1], 100, 4, 0.8), ([40, 33, 2], 20, 3, 1.2),
                                           ([24, 40, 5], 40, 3, 0.9), ([33, 47, 1], 50, 4, 3.0), ([96, 80, 1], 200, 3, 0.7),
                                           ([16, 16, 1], 3, 2, 3.0), ([48, 40, 3], 70, 2, 3.0), ([66000, 6, 1], 12, 2, 1.5)])
-@pytest.mark.parametrize("passes", ["auto", "2"])
+@pytest.mark.parametrize("passes", ["auto", "2", "2 long runs", "1 long runs"])
 def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma, passes, monkeypatch):
     """K3n against K3 on the same inputs: narrow footprints (short lists, empty tiles), the reference's sigma = 3 on
     small volumes (every neuron listed everywhere: groups of 4 and the cross-group path), 2-D and 3-D tiles, ragged
@@ -623,7 +623,9 @@ def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma, passes, monkeypatc
     65536 (IEEE division instead of the shortcut).  Sums agree to fp32
     summation order; the pattern of exact zeros of G is the dense kernel's; two launches agree bitwise."""
     if passes != "auto":   # both launch forms of K3n on this problem (DNMF_LISTS_PASSES, warp_gram_lists.hip)
-        monkeypatch.setenv("DNMF_LISTS_PASSES", passes)
+        monkeypatch.setenv("DNMF_LISTS_PASSES", passes[0])
+        if "long runs" in passes:   # one wave walks the whole frame: runs of tiles with one and the same list
+            monkeypatch.setenv("DNMF_LISTS_CHUNKS", "1")
     from dnmf_amd import ops
     rng = np.random.RandomState(K + sz[0])
     pos = rng.rand(K, 3) * np.array(sz)
@@ -679,6 +681,26 @@ def test_neuron_list_gram_equals_dense(M, O, sz, K, T, sigma, passes, monkeypatc
     order = torch.tensor([T - 1, 0], dtype=torch.int32, device="cuda")
     G3, r3 = dn._gram_rhs(frames[order.long()].contiguous(), order)
     assert torch.equal(G3, Gn[order.long()]) and torch.equal(r3, rn[order.long()])
+
+
+def test_recon_image_from_lists_long_frame_runs(M, O):
+    """The list reconstruction at a frame count where a wave sweeps several runs of 64 frames (the bench's regime: a
+    wave takes ~290 frames of a tile at 512x512x4000; the small cases above give it 16): 200x200, 6000 frames, against a
+    float64 product on the device."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(11)
+    sz, K, T = [200, 200, 1], 12, 6000
+    A = O.gaussian_footprints(sz, rng.rand(K, 3) * np.array(sz), np.full(K, 2.0))
+    A[A < 1e-6] = 0
+    P = int(np.prod(sz))
+    C = torch.rand(K, T, device="cuda")
+    ly = ops.pack_footprints_lists(dev(A), sz)
+    times = torch.randperm(T, device="cuda").to(torch.int32)
+    S = ops.recon_image_lists(ly, K, sz, C, times)
+    ref = (dev(A).reshape(P, K).double() @ C[:, times.long()].double()).T
+    got = ops.halo_interior(S, sz).reshape(T, P)
+    assert float((got.double() - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max())
+    assert border_is_zero(S, sz)
 
 
 @pytest.mark.parametrize("sz,K,sigma", [([64, 48, 1], 30, 1.0), ([70, 130, 1], 100, 0.8), ([40, 33, 2], 20, 1.2),
