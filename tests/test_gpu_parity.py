@@ -436,6 +436,47 @@ def test_full_size_properties(M):
     assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
 
 
+def test_full_size_long_video_lists_vs_dense(M):
+    """The Gram step as the bench runs it -- 512x512, K=100, enough frames (1700) for the library to choose the two
+    launches with ~100 tiles per wave by itself -- against the dense MFMA kernel on the same warped problem: G, r entry by
+    entry on a spread of frames, and the traces after update_footprints through either kernel."""
+    from dnmf_amd import ops
+    from dnmf_amd.WUtils import Simulator
+    torch.manual_seed(3)
+    np.random.seed(3)
+    sz, K, T = [512, 512, 1], 100, 1700
+    frames, positions, _ = Simulator.generate_video_resident(K, T, sz, 3, .2, -120, {"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    frames.clamp_(min=0)
+    assert ops._lib.load().dnmf_warp_gram_rhs_lists_chunks(512, 512, 1, T) == 2 * 10   # two launches, ten chunks each
+
+    def model(kernel):
+        torch.manual_seed(4)
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=positions[:, :, 0].contiguous())
+        dn.verbose, dn.gram_kernel = False, kernel
+        with torch.no_grad():   # a smooth warp per frame, a few voxels at the far corner, off the lattice
+            t = torch.arange(T, device=dn.fp.beta.device, dtype=torch.float32)
+            dn.fp.beta[0, 0] += 0.37 + 1.5 * torch.sin(t / 90.0)
+            dn.fp.beta[0, 1] -= 0.21 + 1.1 * torch.cos(t / 70.0)
+            dn.fp.beta[1, 0] += 2e-3 * torch.sin(t / 50.0)
+            dn.fp.beta[7, 1] += 6e-6 * torch.cos(t / 40.0)
+        return dn
+
+    a, b = model('lists'), model('dense')
+    pick = torch.tensor([0, 1, 2, 411, 850, 1288, 1699], dtype=torch.int32, device="cuda")
+    Gn, rn, _ = ops.warp_gram_rhs_lists(a.fp.packed_lists(), K, sz, a.fp.beta.detach(), None, frames)
+    Gd, rd = ops.warp_gram_rhs(b.fp.packed_footprints(), K, sz, b.fp.beta.detach(), pick, frames, frame_ids=pick)[:2]
+    scale = float(Gd.abs().max())
+    assert float((Gn[pick.long()] - Gd).abs().max()) < 2e-6 * scale
+    assert float((rn[pick.long()] - rd).abs().max()) < 2e-6 * float(rd.abs().max())
+    assert torch.equal((Gn[pick.long()] == 0), (Gd == 0))
+    loader = M.ResidentLoader(frames, sz, 4)
+    a.update_footprints(loader, 4, sz, gamma_c=0, iter_c=5, return_dense=False)
+    b.update_footprints(loader, 4, sz, gamma_c=0, iter_c=5, return_dense=False)
+    assert torch.isfinite(a.C).all()
+    rel = (a.C - b.C).abs() / (b.C.abs() + 1e-6)
+    assert float(rel.max()) < 1e-4, float(rel.max())
+
+
 @pytest.mark.parametrize("passes", ["auto", "2"])
 def test_full_size_neuron_list_path(M, passes, monkeypatch):
     """The bench's default path at its geometry (512x512, K=100): K3n, the list reconstruction and K4 on the slot
