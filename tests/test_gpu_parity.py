@@ -436,6 +436,39 @@ def test_full_size_properties(M):
     assert bool((C >= 0).all()) and bool(torch.isfinite(C).all())
 
 
+def test_full_size_motion_epoch_fused_vs_stepwise(M):
+    """update_motion as the bench runs it (512x512, K=100, shuffled mini-batches of 4, torch Adam at the bench's step
+    size; 600 frames = 150 optimiser steps per epoch, beyond the 64 that the fused epoch takes literally, so the
+    closed-form coasting is in play) against the step-by-step evaluation -- one K2 launch and one optimizer.step() per
+    mini-batch: the displacement of beta agrees to 2e-3 of the largest displacement, the stated Adam tolerance."""
+    from dnmf_amd.WUtils import Simulator
+    torch.manual_seed(5)
+    np.random.seed(5)
+    sz, K, T = [512, 512, 1], 100, 600
+    frames, positions, _ = Simulator.generate_video_resident(K, T, sz, 3, .2, -120, {"sigma": [5, 5, .01], "ls": [10, 10, 10]})
+    frames.clamp_(min=0)
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(6)
+        dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=positions[:, :, 0].contiguous())
+        dn.verbose, dn.fused_motion = False, fused
+        beta0 = dn.fp.beta.detach().clone()
+        opt = torch.optim.Adam([dn.fp.beta], lr=1e-5 * (50.0 / 512) ** 2)
+        loader = M.ResidentLoader(frames, sz, 4, shuffle=True, generator=torch.Generator().manual_seed(7))
+        dn.update_motion(loader, opt, gamma=1, epochs=2)
+        out.append(dn.fp.beta.detach() - beta0)
+    da, db = out
+    assert torch.isfinite(da).all() and float(db.abs().max()) > 0
+    # the three unit coefficients of the identity are left out: at this step size (9.5e-8) an Adam increment is below
+    # their fp32 spacing (1.2e-7), so a run that steps 300 times rounds each of them 300 times and the closed form does
+    # not (test_adam_epoch_against_torch_steps measures both against float64 stepping)
+    free = torch.ones_like(da, dtype=torch.bool)
+    free[1, 0], free[2, 1], free[3, 2] = False, False, False
+    diff = float((da - db)[free].abs().max())
+    assert diff < 2e-3 * float(db[free].abs().max()), diff / float(db[free].abs().max())
+    assert float((da - db).abs().max()) < 16 * 1.2e-7
+
+
 def test_full_size_long_video_lists_vs_dense(M):
     """The Gram step as the bench runs it -- 512x512, K=100, enough frames (1700) for the library to choose the two
     launches with ~100 tiles per wave by itself -- against the dense MFMA kernel on the same warped problem: G, r entry by
