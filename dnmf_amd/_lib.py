@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DNMF_LIB selects another build of the library (kernel-variant timing, ablations); the product default is in-tree
 LIB_PATH = os.environ.get("DNMF_LIB") or os.path.join(_HERE, "libdnmf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 
@@ -45,7 +45,7 @@ SIGNATURES = {
     "dnmf_mu_temporal_slots": (_i, [_vp, _i, _i, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp]),
     "dnmf_warp_gram_rhs_lists_chunks": (_i, [_i, _i, _i, _i]),
     "dnmf_mu_temporal_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _d, _vp, _vp, _vp]),
-    "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
+    "dnmf_spatial_accum": (_i, [_vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     "dnmf_mu_spatial": (_i, [_vp, _vp, _vp, _vp, _d, _l, _i, _vp]),
     "dnmf_image_iwarp_workspace": (_sz, [_i, _i, _i, _i]),
     "dnmf_image_iwarp": (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _sz, _i, _vp, _vp]),

@@ -26,6 +26,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void spatial_accum_kernel(const float *__restrict__ Y, long ldy,
                                                             const int *__restrict__ frame_ids,
                                                             const float *__restrict__ C, long ldc,
+                                                            const float *__restrict__ Ct, long ldct,
                                                             const int *__restrict__ times, int T, long P, int K,
                                                             float *__restrict__ A1, int accumulate) {
     const int lane = threadIdx.x & 63;
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(256) void spatial_accum_kernel(const float *__restr
                 }
             }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) bq[s][b] = C[(long)min(16 * b + ci, K - 1) * ldc + r.col[s]];
+            for (int b = 0; b < NB; ++b) {
+                const int kc = min(16 * b + ci, K - 1);
+                // frame-major traces: the 16 lanes of a frame read one 64-byte run; else 16 rows, 4 bytes of each
+                bq[s][b] = Ct ? Ct[(long)r.col[s] * ldct + kc] : C[(long)kc * ldc + r.col[s]];
+            }
         }
     };
     auto masked = [&](int t0, const float (&raw)[KS][NB], float (&bq)[KS][NB]) {
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(256) void mu_spatial_kernel(float *__restrict__ A, 
 }
 
 template <int NB>
-static void launch_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const int *times,
-                         int T, long P, int K, float *A1, int accumulate, hipStream_t st) {
+static void launch_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const float *Ct, long ldct,
+                         const int *times, int T, long P, int K, float *A1, int accumulate, hipStream_t st) {
     const unsigned nwg = (unsigned)((P + 255) / 256);
-    hipLaunchKernelGGL((spatial_accum_kernel<NB>), dim3(nwg), dim3(256), 0, st, Y, ldy, frame_ids, C, ldc, times, T, P,
+    hipLaunchKernelGGL((spatial_accum_kernel<NB>), dim3(nwg), dim3(256), 0, st, Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P,
                        K, A1, accumulate);
 }
 
@@ -185,23 +190,24 @@ static void launch_accum(const float *Y, long ldy, const int *frame_ids, const f
 
 extern "C" {
 
-int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const int *times,
-                       int T, long P, int K, float *A1, float *Cs, int accumulate, dnmf_stream_t stream) {
+int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const float *Ct, long ldct,
+                       const int *times, int T, long P, int K, float *A1, float *Cs, int accumulate, dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(Y && C && A1 && Cs, DNMF_E_NULL, "dnmf_spatial_accum: NULL buffer");
+    DNMF_REQUIRE(!Ct || ldct >= K, DNMF_E_SHAPE, "dnmf_spatial_accum: ldct=%ld < K=%d", ldct, K);
     DNMF_REQUIRE(T > 0 && P > 0 && K > 0 && ldy >= P && ldc > 0, DNMF_E_SHAPE,
                  "dnmf_spatial_accum: T=%d P=%ld K=%d ldy=%ld ldc=%ld", T, P, K, ldy, ldc);
     DNMF_REQUIRE(K <= 128, DNMF_E_UNSUPPORTED, "dnmf_spatial_accum: K=%d > 128 (not built yet)", K);
     hipStream_t st = (hipStream_t)stream;
     switch ((K + 15) / 16) {
-        case 1: launch_accum<1>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 2: launch_accum<2>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 3: launch_accum<3>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 4: launch_accum<4>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 5: launch_accum<5>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 6: launch_accum<6>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        case 7: launch_accum<7>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
-        default: launch_accum<8>(Y, ldy, frame_ids, C, ldc, times, T, P, K, A1, accumulate, st); break;
+        case 1: launch_accum<1>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 2: launch_accum<2>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 3: launch_accum<3>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 4: launch_accum<4>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 5: launch_accum<5>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 6: launch_accum<6>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        case 7: launch_accum<7>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
+        default: launch_accum<8>(Y, ldy, frame_ids, C, ldc, Ct, ldct, times, T, P, K, A1, accumulate, st); break;
     }
     hipLaunchKernelGGL(trace_gram_kernel, dim3((unsigned)K, (unsigned)((K + TG_L - 1) / TG_L)), dim3(256), 0, st, C, ldc, times, T, K,
                        Cs, accumulate);

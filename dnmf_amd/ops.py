@@ -310,9 +310,11 @@ def spatial_accum(Y, C, frame_ids=None, times=None, A1=None, Cs=None, accumulate
         A1 = torch.empty((P, K), dtype=torch.float32, device=dev)
         Cs = torch.empty((K, K), dtype=torch.float32, device=dev)
         accumulate = False
+    Ct = C.t().contiguous()   # frame-major copy of the traces (K T floats): the kernel's matrix operands in 64-byte runs
     with _timed("spatial_accum"):
-        rc = _lib.load().dnmf_spatial_accum(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), _ptr(tt),
-                                            T, P, K, A1.data_ptr(), Cs.data_ptr(), int(bool(accumulate)), _stream())
+        rc = _lib.load().dnmf_spatial_accum(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), Ct.data_ptr(),
+                                            Ct.stride(0), _ptr(tt), T, P, K, A1.data_ptr(), Cs.data_ptr(),
+                                            int(bool(accumulate)), _stream())
     _lib.check(rc, "dnmf_spatial_accum")
     return A1, Cs
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DNMF_ABI_VERSION 2
+#define DNMF_ABI_VERSION 3
 
 #define DNMF_OK 0
 #define DNMF_E_NULL (-1)      /* required pointer is NULL */
@@ -239,11 +239,14 @@ int dnmf_mu_temporal_step(const float *G, const float *r, const double *Cin, dou
  * DeformableNMF.update_spatial (Demix/dNMF.py:151-160).
  * dnmf_spatial_accum: A1[p,k] = sum_t Y[t,p] C[k,t] (fp32 MFMA, dNMF.py:154) and Cs = C C^T (dNMF.py:153) over
  *   the T frames given: frame t at Y + frame_ids[t]*ldy (NULL -> t), trace column times[t] (NULL -> t);
+ *   Ct: NULL, or the same traces frame-major, Ct[c*ldct + k] = C[k*ldc + c] for every column c the call touches: the
+ *   matrix operands are then read in 64-byte runs instead of 16 rows x 16 bytes per instruction (the kernel's limit);
  *   accumulate != 0 adds to A1 / Cs instead of overwriting (frame chunks).  With the T axis sharded the caller
  *   sums A1 (P,K) and Cs (K,K) over ranks (RCCL all-reduce) before dnmf_mu_spatial.
  * dnmf_mu_spatial: A <- A * A1 / (A Cs + gamma D + 1e-32) in place (dNMF.py:155-159); D (P,K) or NULL. */
-int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const int *times,
-                       int T, long P, int K, float *A1, float *Cs, int accumulate, dnmf_stream_t stream);
+int dnmf_spatial_accum(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const float *Ct,
+                       long ldct, const int *times, int T, long P, int K, float *A1, float *Cs, int accumulate,
+                       dnmf_stream_t stream);
 int dnmf_mu_spatial(float *A, const float *A1, const float *Cs, const float *D, double gamma, long P, int K,
                     dnmf_stream_t stream);
 
