@@ -39,6 +39,7 @@
 // goes to a slab per (frame, chunk); the finish kernel adds the chunks in order and scatters the slots into dense
 // G (K,K), r (K).
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "common.hpp"
@@ -957,6 +958,10 @@ static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, h
         return;
     }
     // fork: the second pass on the side stream behind the lists, join before anything that follows on `st`
+    // (one host thread at a time through the fork / join: the two events are shared, and a wait takes whatever was last
+    // recorded on its event when it is enqueued)
+    static std::mutex fork_join;
+    std::lock_guard<std::mutex> hold(fork_join);
     SideStream &ss = side_stream();
     if (ss.stream) {
         hipEventRecord(ss.fork, st);
