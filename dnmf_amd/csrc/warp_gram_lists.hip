@@ -97,8 +97,9 @@ struct ListParams {
     const int *frame_ids;
     float *slab;  // (B, tables, nslot): table c of a frame from chunk c; with two launches table nchunks + c from the second
     unsigned long long *tile_masks;  // (B, ntiles, NW): the neuron list of every tile of every frame
-    int2 *tile_region;     // (B, ntiles): first halo row / first float of a halo row of the tile's tap region; x < 0: the
-                           // taps do not fit LISTS_RR x LISTS_RC (or Z > 1): direct gathers
+    int4 *tile_desc;       // (B, ntiles): x = the tile's tap region packed as first halo row << 16 | first float of a halo row,
+                           // -1: the taps do not fit LISTS_RR x LISTS_RC (or Z > 1): direct gathers; y = the list's first
+                           // four neurons, one per byte in ascending order (0xff past the end); z = its length
     int nchunks, chunk_len;
     int tables;            // nchunks, or 2 nchunks when the long-list tiles go in a launch of their own
     int lgx, lgy, lgz;  // tile = (LISTS_VPL << lgx) x (1 << lgy) x (1 << lgz) voxels, lgx + lgy + lgz = 6: 8 x 32 x 1 for
@@ -208,7 +209,17 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
         const int r0 = min(ax + HALO, p.hl.Xp - LISTS_RR), c0 = min((ay + HALO) & ~3, p.hl.rowf - LISTS_RC);
         if (cx >= ax && cy >= ay && cx + HALO - r0 < LISTS_RR && cy + HALO - c0 < LISTS_RC) reg = make_int2(r0, c0);
     }
-    p.tile_region[id] = reg;
+    int nlist = 0;
+    unsigned ids = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        unsigned long long rem = m[w];
+        while (rem) {
+            if (nlist < 4) ids = (ids & ~(0xffu << (8 * nlist))) | ((unsigned)(64 * w + __builtin_ctzll(rem)) << (8 * nlist));
+            ++nlist, rem &= rem - 1;
+        }
+    }
+    p.tile_desc[id] = make_int4(reg.x < 0 ? -1 : (reg.x << 16 | reg.y), (int)ids, nlist, 0);
 }
 
 // PASS 1: the tiles with at most LISTS_NG neurons; PASS 2: the other tiles, into tables of their own (the consumers sum
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     constexpr int PPR = LISTS_RC / 4;
     const int piece_row[2] = {lane / PPR, (lane + 64) / PPR};
     const int piece_c4[2] = {lane - piece_row[0] * PPR, lane + 64 - piece_row[1] * PPR};
-    const int2 *__restrict__ regions = p.tile_region + (long)b * p.ntiles;
+    const int4 *__restrict__ descs = p.tile_desc + (long)b * p.ntiles;
 
     const int lgx = p.lgx, lgz = p.lgz;
     const int lgy = p.lgy;
@@ -258,7 +269,6 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     const int q_end = min(q_begin + p.chunk_len, p.ntiles);
     const unsigned long long *__restrict__ masks = p.tile_masks + (long)b * p.ntiles * NW;
     unsigned long long n_eval = 0, n_pair = 0;  // wave-uniform
-    bool any_tile = false;                      // wave-uniform
 #ifdef DNMF_K3N_STAMPS
     // diagnostic build only (tools/k3n_stamps.py): wave cycles per section of the tile loop into counters[2..8], then
     // the number of non-empty tiles, of long-list tiles and of flushed runs
@@ -355,23 +365,26 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     unsigned long long prev[NW];
 #pragma unroll
     for (int wd = 0; wd < NW; ++wd) prev[wd] = 0;
+    int prev_ids = -1;   // PASS 1: the previous tile's list (a list of one to four neurons is never -1: neuron 255 in all
+                         // four bytes would need four equal entries)
 
     // The lists and regions of 64 tiles at a time, one tile per lane (a per-tile load of these wave-uniform words would
     // put a full memory round trip in front of every tile); a tile then takes its words from that lane.
     for (int q0 = q_begin; q0 < q_end; q0 += 64) {
       unsigned my_lo[NW], my_hi[NW];
       int my_reg = -1;   // region origin packed as row << 16 | column (both below 65536: checked on the host), -1: none
+      int my_ids = -1, my_n = 0;   // PASS 1: the list itself (at most four neurons: one per byte) and its length
       {
           const int ql = min(q0 + lane, q_end - 1);
+          if (PASS != 1) {   // the short-list pass needs no masks: its lists fit the descriptor
 #pragma unroll
-          for (int wd = 0; wd < NW; ++wd) {
-              const unsigned long long m = masks[(long)ql * NW + wd];
-              my_lo[wd] = (unsigned)m, my_hi[wd] = (unsigned)(m >> 32);
+              for (int wd = 0; wd < NW; ++wd) {
+                  const unsigned long long m = masks[(long)ql * NW + wd];
+                  my_lo[wd] = (unsigned)m, my_hi[wd] = (unsigned)(m >> 32);
+              }
           }
-          if (!HASZ) {
-              const int2 rg = regions[ql];
-              my_reg = rg.x < 0 ? -1 : (rg.x << 16 | rg.y);
-          }
+          const int4 dsc = descs[ql];
+          my_reg = HASZ ? -1 : dsc.x, my_ids = dsc.y, my_n = dsc.z;
       }
       if (LONGPASS) {   // nothing for this pass among these 64 tiles?
           int myn = 0;
@@ -385,23 +398,33 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         unsigned long long msk[NW];
         int n = 0;  // wave-uniform
         bool same = true;
+        int ids = -1;
+        if (PASS == 1) {
+            n = __builtin_amdgcn_readlane(my_n, jl);
+            if (n == 0 || n > LISTS_NG) continue;
+            ids = __builtin_amdgcn_readlane(my_ids, jl);
+            same = ids == prev_ids;
+            prev_ids = ids;
+        } else {
 #pragma unroll
-        for (int wd = 0; wd < NW; ++wd) {
-            msk[wd] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)my_hi[wd], jl) << 32) |
-                      (unsigned)__builtin_amdgcn_readlane((int)my_lo[wd], jl);
-            n += __builtin_popcountll(msk[wd]);
-            same = same && msk[wd] == prev[wd];
+            for (int wd = 0; wd < NW; ++wd) {
+                msk[wd] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)my_hi[wd], jl) << 32) |
+                          (unsigned)__builtin_amdgcn_readlane((int)my_lo[wd], jl);
+                n += __builtin_popcountll(msk[wd]);
+                same = same && msk[wd] == prev[wd];
+            }
         }
         if (n == 0 || (PASS == 1 && n > LISTS_NG) || (PASS == 2 && n <= LISTS_NG)) continue;
-        any_tile = true;
         DNMF_STAMP(0)   // tile bookkeeping
 #ifdef DNMF_K3N_STAMPS
         st_acc[7] += 1, st_acc[8] += n > LISTS_NG, st_acc[9] += (!same || n > LISTS_NG) && run_n != 0;   // tiles, long lists, flushes
 #endif
         if (!same || n > LISTS_NG) flush();
         DNMF_STAMP(1)   // reductions of a finished run
+        if (PASS != 1) {
 #pragma unroll
-        for (int wd = 0; wd < NW; ++wd) prev[wd] = n > LISTS_NG ? 0 : msk[wd];
+            for (int wd = 0; wd < NW; ++wd) prev[wd] = n > LISTS_NG ? 0 : msk[wd];
+        }
 
         const int qx = q % p.ntx, rest = q / p.ntx;
         if (rest != row_of_c) {
@@ -580,11 +603,16 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         n_eval += n, n_pair += n * (n + 1) / 2;
         if (PASS != 2 && n <= LISTS_NG) {
             // the usual case: the whole list in registers; sums join the pending run (same list) or start one
-            unsigned long long rem[NW];
-#pragma unroll
-            for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
             int ks[LISTS_NG];
-            take_ids(rem, ks);
+            if (PASS == 1) {   // the list came with the tile's descriptor
+#pragma unroll
+                for (int i = 0; i < LISTS_NG; ++i) ks[i] = i < n ? (int)(((unsigned)ids >> (8 * i)) & 0xffu) : -1;
+            } else {
+                unsigned long long rem[NW];
+#pragma unroll
+                for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
+                take_ids(rem, ks);
+            }
             const bool fresh = run_n == 0;
             auto go = [&](auto nn) {
                 constexpr int N = decltype(nn)::value;
@@ -1026,12 +1054,17 @@ static size_t lists_slab_bytes(int nslot, int B) {
     return ((size_t)B * (size_t)(2 * want) * (size_t)nslot * sizeof(float) + 255) / 256 * 256;   // up to two tables per chunk
 }
 
+// the tiles' list words, rounded up so that the 16-byte descriptors behind them are aligned
+static size_t lists_masks_bytes(int K, int B, int ntiles) {
+    return ((size_t)B * ntiles * dnmf::lists_words(K) * sizeof(unsigned long long) + 15) / 16 * 16;
+}
+
 size_t dnmf_warp_gram_rhs_lists_workspace(int nslot, int K, int X, int Y, int Z, int B) {
     using namespace dnmf;
     if (nslot <= 0 || B <= 0 || K <= 0 || K > 64 * LISTS_MAXW || X <= 0 || Y <= 0 || Z <= 0) return 0;
     int lgx, lgy, lgz, ntx, nty, ntz, ntiles;
     lists_tile_shape(make_volume(X, Y, Z), lgx, lgy, lgz, ntx, nty, ntz, ntiles);
-    return lists_slab_bytes(nslot, B) + (size_t)B * ntiles * (lists_words(K) * sizeof(unsigned long long) + sizeof(int2));
+    return lists_slab_bytes(nslot, B) + lists_masks_bytes(K, B, ntiles) + (size_t)B * ntiles * sizeof(int4);
 }
 
 int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_slot, const void *axis_masks, int nslot, int K,
@@ -1070,7 +1103,7 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
     const long nitems = (long)p.nchunks * B;
     const unsigned nwg = (unsigned)((nitems + 3) / 4);
     const int nw = lists_words(K);
-    p.tile_region = reinterpret_cast<int2 *>(p.tile_masks + (size_t)B * p.ntiles * lists_words(K));
+    p.tile_desc = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.tile_masks) + lists_masks_bytes(K, B, p.ntiles));
     // four slot tables (padded to 16 bytes), then for Z == 1 the four waves' staging regions
     const size_t lds = (((size_t)4 * nslot + 3) & ~(size_t)3) * sizeof(float) +
                        (Z == 1 ? (size_t)4 * LISTS_NG * LISTS_REGION * sizeof(float) : 0);

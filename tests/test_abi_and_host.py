@@ -61,11 +61,11 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert lib.dnmf_halo_voxels(512, 512, 1) == 516 * 544 and lib.dnmf_halo_voxels(4, 5, 3) == 8 * 32
     assert lib.dnmf_lists_axis_masks_bytes(512, 512, 1, 100) == 2 * (512 + 512 + 1 + 6) * 2 * 8
     # slot tables (5 chunks per frame at B = 4000, two tables per chunk: one per launch; rounded up to 256 bytes), then one
-    # 2-word list and one region record per frame and tile
+    # 2-word list and one 16-byte descriptor per frame and tile
     slab = (4000 * 2 * 5 * 461 * 4 + 255) // 256 * 256
     assert lib.dnmf_warp_gram_rhs_lists_chunks(512, 512, 1, 4000) == 10     # tables a consumer sums per frame
     assert lib.dnmf_warp_gram_rhs_lists_chunks(512, 512, 1, 400) == 41      # short video: one launch, one table per chunk
-    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 100, 512, 512, 1, 4000) == slab + 4000 * 1024 * (2 * 8 + 8)
+    assert lib.dnmf_warp_gram_rhs_lists_workspace(461, 100, 512, 512, 1, 4000) == slab + 4000 * 1024 * (2 * 8 + 16)
     rc = lib.dnmf_warp_gram_rhs_lists(addr, addr, addr, addr, 5000, 3, 4, 4, 1, addr, 1, None, 1, addr, 16, None, addr, addr,
                                       addr, 1 << 20, None, None)
     assert rc == -3 and b"pattern slots" in lib.dnmf_last_error()
