@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
             ++nlist, rem &= rem - 1;
         }
     }
-    p.tile_desc[id] = make_int4(reg.x < 0 ? -1 : (reg.x << 16 | reg.y), (int)ids, nlist, 0);
+    // w: the tile's place, qx | (qy * ntz + qz) << 16 when both fit 16 bits (else -1: the kernel divides)
+    const int place = (qx < 65536 && rest < 32768) ? (qx | rest << 16) : -1;
+    p.tile_desc[id] = make_int4(reg.x < 0 ? -1 : (reg.x << 16 | reg.y), (int)ids, nlist, place);
 }
 
 // PASS 1: the tiles with at most LISTS_NG neurons; PASS 2: the other tiles, into tables of their own (the consumers sum
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
       unsigned my_lo[NW], my_hi[NW];
       int my_reg = -1;   // region origin packed as row << 16 | column (both below 65536: checked on the host), -1: none
       int my_ids = -1, my_n = 0;   // PASS 1: the list itself (at most four neurons: one per byte) and its length
+      int my_place = -1;           // qx | tile row << 16 (-1: not packed)
       {
           const int ql = min(q0 + lane, q_end - 1);
           if (PASS != 1) {   // the short-list pass needs no masks: its lists fit the descriptor
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
               }
           }
           const int4 dsc = descs[ql];
-          my_reg = HASZ ? -1 : dsc.x, my_ids = dsc.y, my_n = dsc.z;
+          my_reg = HASZ ? -1 : dsc.x, my_ids = dsc.y, my_n = dsc.z, my_place = dsc.w;
       }
       if (LONGPASS) {   // nothing for this pass among these 64 tiles?
           int myn = 0;
@@ -426,9 +429,12 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             for (int wd = 0; wd < NW; ++wd) prev[wd] = n > LISTS_NG ? 0 : msk[wd];
         }
 
-        const int qx = q % p.ntx, rest = q / p.ntx;
+        // the tile's column and row in the walk: from its descriptor (integer divisions by run-time values cost the
+        // scalar unit ~20 instructions each)
+        const int place = __builtin_amdgcn_readlane(my_place, jl);
+        const int qx = place >= 0 ? (place & 0xffff) : q % p.ntx, rest = place >= 0 ? (place >> 16) : q / p.ntx;
         if (rest != row_of_c) {
-            const int qz = rest % p.ntz, qy = rest / p.ntz;
+            const int qz = HASZ ? rest % p.ntz : 0, qy = HASZ ? rest / p.ntz : rest;
             mono = monomials<HASZ>(0.0f, (float)((qy << lgy) + ly), (float)((qz << lgz) + lz));
 #if DNMF_K3N_DIRECT
 #pragma unroll
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #endif
             row_of_c = rest;
         }
-        const int qz = rest % p.ntz, qy = rest / p.ntz;
+        const int qz = HASZ ? rest % p.ntz : 0, qy = HASZ ? rest / p.ntz : rest;
         const int y = (qy << lgy) + ly, z = (qz << lgz) + lz;
         const bool yz_in = y < vol.Y && z < vol.Z;
         // staged gathers for this tile?  (wave-uniform)
