@@ -63,6 +63,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DNMF_K3N_DIRECT
 #define DNMF_K3N_DIRECT 0
 #endif
+#ifndef DNMF_K3N_EARLY1
+#define DNMF_K3N_EARLY1 1
+#endif
 #ifndef DNMF_K3N_WAVES
 #define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
 #endif
@@ -465,6 +468,33 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
         const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
 
+        // staged: the region of neuron k into staging slot i (two sixteen-byte pieces per lane, 120 in all) ...
+        auto stage_load = [&](int k, f32x4 (&piece)[2]) {
+            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane + reg_goff;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned o = (unsigned)(piece_row[j] * hl.row4 + piece_c4[j] * 16);
+                asm("" : "+v"(o));
+                piece[j] = (j == 0 || lane + 64 < LISTS_REGION / 4) ? *reinterpret_cast<const f32x4 *>(Ak + o)
+                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto stage_store = [&](int i, const f32x4 (&piece)[2]) {
+            char *dst = stage_lds + i * (LISTS_REGION * 4);
+            *reinterpret_cast<f32x4 *>(dst + lane * 16) = piece[0];
+            if (lane + 64 < LISTS_REGION / 4) *reinterpret_cast<f32x4 *>(dst + (lane + 64) * 16) = piece[1];
+        };
+#if DNMF_K3N_EARLY1
+        // The region of the list's first neuron is requested here, ahead of the coordinate arithmetic, which hides its
+        // latency (3.10 -> 3.05 ms per 4000 frames at 512x512, K=100).  Eight registers in flight fit; the first TWO
+        // neurons' regions (sixteen) spill: 3.98 ms.
+        f32x4 early[2];
+        if (PASS == 1 && staged) {
+            stage_load((int)((unsigned)ids & 0xffu), early);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+
         // ---- taps of this lane's four voxels: byte offsets of the two x-columns of the tap cell, weights ------------
         unsigned off[LISTS_VPL][NTAP / 2];   // [.][dx + 2 dz]: the (y, y+1) pair is one eight-byte load; a staged tile
                                              // keeps the LDS byte offset of the base corner inside a region in [.][0]
@@ -566,22 +596,6 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                 a[v] = s;
             }
         };
-        // staged: the region of neuron k into staging slot i (two sixteen-byte pieces per lane, 120 in all) ...
-        auto stage_load = [&](int k, f32x4 (&piece)[2]) {
-            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane + reg_goff;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                unsigned o = (unsigned)(piece_row[j] * hl.row4 + piece_c4[j] * 16);
-                asm("" : "+v"(o));
-                piece[j] = (j == 0 || lane + 64 < LISTS_REGION / 4) ? *reinterpret_cast<const f32x4 *>(Ak + o)
-                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        auto stage_store = [&](int i, const f32x4 (&piece)[2]) {
-            char *dst = stage_lds + i * (LISTS_REGION * 4);
-            *reinterpret_cast<f32x4 *>(dst + lane * 16) = piece[0];
-            if (lane + 64 < LISTS_REGION / 4) *reinterpret_cast<f32x4 *>(dst + (lane + 64) * 16) = piece[1];
-        };
         // ... and the warped values of the lane's voxels from there
         auto eval_staged = [&](int i, float (&a)[LISTS_VPL]) {
             const char *src0 = stage_lds + i * (LISTS_REGION * 4);
@@ -630,7 +644,16 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                         f32x4 piece[2][2];
 #ifndef DNMF_K3N_ABL_STAGE   // timing ablation: taps from whatever the LDS holds
 #pragma unroll
-                        for (int i = i0; i < N && i < i0 + 2; ++i) stage_load(ks[i], piece[i - i0]);
+                        for (int i = i0; i < N && i < i0 + 2; ++i) {
+#if DNMF_K3N_EARLY1
+                            if (PASS == 1 && i == 0) {
+                                piece[0][0] = early[0], piece[0][1] = early[1];
+                                continue;
+                            }
+
+#endif
+                            stage_load(ks[i], piece[i - i0]);
+                        }
 #pragma unroll
                         for (int i = i0; i < N && i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
 #endif
