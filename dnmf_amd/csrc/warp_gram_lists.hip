@@ -1020,13 +1020,14 @@ static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, h
     static std::mutex fork_join;
     std::lock_guard<std::mutex> hold(fork_join);
     SideStream &ss = side_stream();
-    if (ss.stream) {
-        hipEventRecord(ss.fork, st);
-        hipStreamWaitEvent(ss.stream, ss.fork, 0);
+    const bool forked = ss.stream && hipEventRecord(ss.fork, st) == hipSuccess &&
+                        hipStreamWaitEvent(ss.stream, ss.fork, 0) == hipSuccess;
+    if (forked) {
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, ss.stream, p);
-        hipEventRecord(ss.join, ss.stream);
+        const bool recorded = hipEventRecord(ss.join, ss.stream) == hipSuccess;
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
-        hipStreamWaitEvent(st, ss.join, 0);
+        if (!recorded || hipStreamWaitEvent(st, ss.join, 0) != hipSuccess)
+            (void)hipStreamSynchronize(ss.stream);   // the join could not be enqueued: wait for the side stream here
     } else {   // no side stream to be had: one after the other
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
         hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
