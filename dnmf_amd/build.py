@@ -1,6 +1,6 @@
 """Build libdnmf_hip.so (gfx950) in-tree with hipcc.
 
-    python -m dnmf_amd.build [--force] [--out PATH] [-DNAME=VALUE | -fFLAG | -mFLAG ...]
+    python -m dnmf_amd.build [--force] [--out PATH] [--only FILE.hip[,FILE.hip]] [-DNAME=VALUE | -fFLAG | -mFLAG ...]
 
 ``--out`` / ``-D``: a kernel-variant build beside the product library (timing studies; ``DNMF_LIB=PATH`` selects it).
 
@@ -33,21 +33,60 @@ def _stale() -> bool:
 
 # what the last build_library() call did: "compiled" or "reused" (the library was newer than every source)
 LAST_ACTION = None
+# flags of single files (measured per kernel)
+PER_FILE_FLAGS = {
+    # K2: the SLP vectoriser's packed fp32 operations issue no faster than two scalar ones and cost register shuffles
+    # (512x512x2x4000: 6.55 ms against 6.93; Z == 1 unchanged)
+    "warp_recon_grad.hip": ["-fno-slp-vectorize"],
+}
 
 
-def build_library(force: bool = False, verbose: bool = True, out: str | None = None, defines=()) -> str:
-    """Compile every HIP source into ``dnmf_amd/libdnmf_hip.so`` (or ``out``); returns its path."""
+def _compile_one(job):
+    cmd, src = job
+    subprocess.run(cmd, check=True)
+    return src
+
+
+def build_library(force: bool = False, verbose: bool = True, out: str | None = None, defines=(), only=None) -> str:
+    """Compile every HIP source into ``dnmf_amd/libdnmf_hip.so`` (or ``out``); returns its path.
+
+    One object per source under ``build/obj/<key>/`` (key = the extra flags), compiled in parallel and reused while it is
+    newer than its source and every header: an edit to one kernel file recompiles that file only.  ``only``: source
+    names the extra ``defines`` apply to (a variant of one kernel file links against the product objects of the others)."""
     global LAST_ACTION
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     target = out or LIB
     if out is None and not force and not _stale():
         LAST_ACTION = "reused"
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(os.path.abspath(target)), exist_ok=True)
-    cmd = [hipcc, *FLAGS, *defines, *[os.path.join(CSRC, s) for s in SOURCES], "-o", target, "-ldl"]
+    cflags = [f for f in FLAGS if f != "-shared"]
+
+    def objdir_for(extra):
+        key = hashlib.sha1(" ".join([hipcc, *cflags, *extra]).encode()).hexdigest()[:12]
+        d = os.path.join(HERE, "..", "build", "obj", key)
+        os.makedirs(d, exist_ok=True)
+        return d
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(HERE, "..", "include", "dnmf_hip.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    jobs, objs = [], []
+    for s in SOURCES:
+        extra = [*PER_FILE_FLAGS.get(s, []), *(defines if (only is None or s in only) else [])]
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir_for(extra), s + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append(([hipcc, *cflags, *extra, "-c", src, "-o", obj], s))
     if verbose:
-        print("[dnmf_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print(f"[dnmf_amd.build] {hipcc} {' '.join([*cflags, *defines])}: compiling {[j[1] for j in jobs]}, "
+              f"reusing {len(objs) - len(jobs)} objects", flush=True)
+    workers = max(1, min(len(jobs), (os.cpu_count() or 2)))
+    if jobs:
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(_compile_one, jobs))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", target, "-ldl"], check=True)
     LAST_ACTION = "compiled"
     return target
 
@@ -55,4 +94,6 @@ def build_library(force: bool = False, verbose: bool = True, out: str | None = N
 if __name__ == "__main__":
     args = sys.argv[1:]
     out = args[args.index("--out") + 1] if "--out" in args else None
-    print(build_library(force="--force" in args, out=out, defines=[a for a in args if a.startswith(("-D", "-f", "-m"))]))
+    only = args[args.index("--only") + 1].split(",") if "--only" in args else None
+    print(build_library(force="--force" in args, out=out, defines=[a for a in args if a.startswith(("-D", "-f", "-m"))],
+                        only=only))

@@ -320,6 +320,20 @@ __device__ __forceinline__ bool tap_range(const float *b, const Volume &vol, int
     return true;
 }
 
+// sum over the 64 lanes, valid in lane 63 (fixed tree: row prefix sums, then the row totals)
+__device__ __forceinline__ float wave_sum_last(float v) {
+#define DNMF_STEP(ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true));
+    DNMF_STEP(0x111, 0xf)  // row_shr:1
+    DNMF_STEP(0x112, 0xf)  // row_shr:2
+    DNMF_STEP(0x114, 0xf)  // row_shr:4
+    DNMF_STEP(0x118, 0xf)  // row_shr:8 -> lane 15 of a row holds the row sum
+    DNMF_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    DNMF_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef DNMF_STEP
+    return v;
+}
+
 // Load the 30 coefficients of frame t from beta (10,3,T) into b[a*3+d].
 __device__ __forceinline__ void load_beta(const float *__restrict__ beta, int T, int t, float *b) {
 #pragma unroll

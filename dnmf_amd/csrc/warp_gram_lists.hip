@@ -112,20 +112,6 @@ struct ListParams {
     unsigned long long *counters;  // optional: [0] += (tile, neuron) evaluations, [1] += (tile, pair) sums
 };
 
-// sum over the 64 lanes, valid in lane 63 (fixed tree: row prefix sums, then the row totals)
-__device__ __forceinline__ float wave_sum_last(float v) {
-#define DNMF_STEP(ctrl, rmask) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true));
-    DNMF_STEP(0x111, 0xf)  // row_shr:1
-    DNMF_STEP(0x112, 0xf)  // row_shr:2
-    DNMF_STEP(0x114, 0xf)  // row_shr:4
-    DNMF_STEP(0x118, 0xf)  // row_shr:8 -> lane 15 of a row holds the row sum
-    DNMF_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
-    DNMF_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
-#undef DNMF_STEP
-    return v;
-}
-
 // ---- neuron lists of the tiles ---------------------------------------------------------------------------
 // axis_masks: for axis d (0,1,2) two tables of S_d + 2 entries of NW 64-bit words:
 //   LO_d[i + 1] = { k : bbox_lo_d[k] <= i },  i = -1 .. S_d   (entry 0 is the empty set)

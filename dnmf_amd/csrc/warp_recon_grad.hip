@@ -8,28 +8,41 @@
 //   d A_tC / d q = sum_corners (d w_c / d q) s(corner_c(v))          (in-bounds corners only)
 //   d L / d beta[a,d] = 2/(B P) sum_v basis_a(v) (A_tC(v) - y(v)) dA_tC/dq_d(v)
 // The factor (S-1)/2 of grid_sample's backward and the 2/(S-1) of the normalisation cancel.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dnmf {
 
-constexpr int K2_ROWS = 16;           // voxels per lane: consecutive x
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // four floats at an 8-byte aligned address
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+constexpr int K2_ROWS = 32;           // voxels per lane: consecutive x (the block reduction is paid once per K2_ROWS voxels)
 constexpr int K2_COLS = 256;          // positions of the (y,z) plane per block: 64 lanes x 4 waves
 constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
 #ifndef DNMF_K2_UNROLL
 #define DNMF_K2_UNROLL 2
 #endif
-constexpr int K2_UNROLL = DNMF_K2_UNROLL;  // rows requested together
-static_assert(K2_ROWS % K2_UNROLL == 0, "the row loop takes K2_UNROLL rows at a time");
+#ifndef DNMF_K2_UNROLL_Z
+#define DNMF_K2_UNROLL_Z 1
+#endif
+#ifndef DNMF_K2_WAVES_Z
+#define DNMF_K2_WAVES_Z 1
+#endif
+constexpr int K2_UNROLL = DNMF_K2_UNROLL;      // rows requested together (Z == 1)
+constexpr int K2_UNROLL_Z = DNMF_K2_UNROLL_Z;  // the same for Z >= 2
+static_assert(K2_ROWS % K2_UNROLL == 0 && K2_ROWS % K2_UNROLL_Z == 0, "the row loop takes K2_UNROLL rows at a time");
 
+// (sum_loss_kernel only; the main kernel reduces with DPP adds, common.hpp: wave_sum_last)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-// Work layout: a block owns 16 x-rows by 256 consecutive positions of the (y,z) plane (lane = position, so the frame
+// Work layout: a block owns K2_ROWS x-rows by 256 consecutive positions of the (y,z) plane (lane = position, so the frame
 // and the reconstruction image are read in 256-byte runs and the taps of neighbouring lanes share cache lines); a
-// thread walks down its 16 rows with (y,z) fixed: the monomials without x are per-thread constants, and x, x^2 are the
+// thread walks down its rows with (y,z) fixed: the monomials without x are per-thread constants, and x, x^2 are the
 // same for the whole block: they come from a table (scalar loads).  The polynomial itself is the reference's chain of
 // ten (six for Z = 1) fused multiply-adds, in its order (common.hpp: poly_a).
 //
@@ -38,11 +51,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 // same zeros).  Per voxel that leaves: two FMAs per coordinate, the fp32 normalise / un-normalise round trip of the
 // reference, one clamp + floor + two weights per axis, one base offset, the taps, the blends.
 //
-// HASZ = false is the Z == 1 specialisation: two coordinates, four taps, and only the six basis terms without z
+// ZM = 1 is the Z == 1 specialisation: two coordinates, four taps, and only the six basis terms without z
 // (the other 18 gradient sums are identically zero and are written as such).  PLAIN = the fit step's call (frames
 // given, no upstream gradient, A_tC not wanted): the row loop then has no branches.
-template <bool HASZ, int FAST, bool F32OFF, bool PLAIN>
-__global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
+//
+// Z >= 2 (ZM = 2: Z == 2, ZM = 3: Z > 2).  The two z-taps of a corner are adjacent floats of a halo row
+// ((y + HALO) Z + z): they are fetched as ONE pair (izc, izc + 1) with izc = the base slice clamped into [0, Z - 2], i.e.
+// the pair inside the volume that holds every in-range z-tap of the sample; a tap outside [0, Z) has no partner in the
+// pair and its weight is dropped -- what grid_sample's per-corner bounds test does -- by giving each member of the pair
+// the weight of the tap it stands for (or 0).  For Z == 2 the pair is always (0, 1) and the pairs of the corners y and
+// y + 1 are 16 contiguous bytes: a voxel is TWO sixteen-byte gathers (one per x-corner; round 2 issued eight four-byte
+// ones, 8.1 ms per 4000 frames at 512x512x2); for Z > 2 four eight-byte ones.
+template <int ZM, int FAST, bool F32OFF, bool PLAIN>
+__global__ __launch_bounds__(256, (ZM > 1 ? DNMF_K2_WAVES_Z : 1)) void warp_recon_grad_kernel(const float *__restrict__ S, long lds,
                                                               const int *__restrict__ s_ids,
                                                               const float *__restrict__ frames, long ldf,
                                                               const int *__restrict__ frame_ids,
@@ -51,6 +72,9 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
                                                               const int *__restrict__ times,
                                                               float *__restrict__ recon, float *__restrict__ partial,
                                                               const float2 *__restrict__ xtab, int nub) {
+    constexpr bool HASZ = ZM > 1;
+    constexpr bool ZPAIR = ZM == 2;                  // a thread owns BOTH slices of its (x, y) columns
+    constexpr int NV = ZPAIR ? 2 : 1;                // voxels per thread and row
     constexpr int ND = HASZ ? 3 : 2;                 // warped coordinates that exist
     constexpr int NA = HASZ ? 10 : 6;                // basis terms that are not identically zero
     constexpr int BASIS_ID[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};  // z-free terms first
@@ -63,118 +87,194 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     load_beta(beta, T, times[b], bt);
 
     // y and z are fixed along a thread's rows, so inside the loop only the moments of the per-voxel term over x are
-    // accumulated: mom[m][d] = sum_i (resid g_d)_i x_i^m, m = 0, 1, 2; the ten basis sums follow from them afterwards
-    float mom[3][ND];
+    // accumulated: mom[.][m][d] = sum_i (resid g_d)_i x_i^m, m = 0, 1, 2; the ten basis sums follow from them afterwards
+    float mom[NV][3][ND];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int d = 0; d < ND; ++d) mom[m][d] = 0.0f;
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) mom[v][m][d] = 0.0f;
     float sq = 0.0f;
     const int YZ = vol.Y * vol.Z;
+    const int plane = ZPAIR ? vol.Y : YZ;              // positions the lanes of a frame's blocks run over
     const int bu = blockIdx.x % nub, bx = blockIdx.x / nub;
-    const int u = bu * K2_COLS + threadIdx.x;          // position in the (y,z) plane
-    const int yy = HASZ ? div_small(u, vol.Z, vol.rcp_z) : u;
-    const int z = HASZ ? u - yy * vol.Z : 0;
+    const int u = bu * K2_COLS + threadIdx.x;          // position in the (y,z) plane; Z == 2: y
+    const int yy = (HASZ && !ZPAIR) ? div_small(u, vol.Z, vol.rcp_z) : u;
+    const int z = (HASZ && !ZPAIR) ? u - yy * vol.Z : 0;
     const float yf = (float)yy, zf = (float)z;
 
-    if (u < YZ) {
+    if (u < plane) {
         float b2[30];
         double_beta(bt, b2);
-        Monomials<HASZ> mono = monomials<HASZ>(0.0f, yf, zf);   // y, z, y^2, z^2, yz: fixed along the rows
+        const Monomials<true> mono = monomials<true>(0.0f, yf, zf);   // y, z, y^2, z^2, yz: fixed along the rows
         const int x_first = bx * K2_ROWS;
         const int nrow = min(K2_ROWS, vol.X - x_first);
 
         // A row is handled in two steps so that the loop below can keep the taps of the next rows in flight while
         // it blends the current ones: request() = coordinates, weights, tap offsets, loads; consume() = the blends,
         // the residual and the moment sums.
+        struct Vox {
+            float sv[HASZ ? 2 : 1][2][2];  // [dz][dy][dx]
+            float wx1, wy1, wzm[2], vz[2];
+            float other;                  // frame value, or the caller's upstream gradient
+        };
         struct Req {
             float2 xv;                    // (x, x*x): block-uniform
-            float sv[HASZ ? 2 : 1][2][2];  // [dz][dy][dx]
-            float wx[2], wy[2], wzm[2], vz[2];
-            float other;                  // frame value, or the caller's upstream gradient
             long prow;
+            Vox v[NV];
         };
-        unsigned u4 = (unsigned)u * 4u;
+        unsigned u4 = (unsigned)u * (4u * NV);
+        // ZC: the voxel's slice when it is known at compile time (Z == 2: 0 or 1), else -1.  z == 0: the four terms with z
+        // add an exact zero each (the Z == 1 chain); z == 1: their monomials are 1, 1, x, y.
+        auto taps = [&](const float2 xv, float xy, auto zc, Vox &q) {
+            constexpr int ZC = decltype(zc)::value;
+            float a[3] = {0.0f, 0.0f, 0.0f};
+            if constexpr (ZC == 0) {
+                Monomials<false> m;
+                m.x = xv.x, m.y = yf, m.z = 0.0f, m.xx = xv.y, m.yy = mono.yy, m.zz = 0.0f, m.xy = xy, m.xz = 0.0f, m.yz = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a[d] = poly_a<false>(b2, d, m);
+            } else {
+                Monomials<true> m = mono;
+                m.x = xv.x, m.xx = xv.y, m.xy = xy;
+                if constexpr (ZC == 1) {
+                    m.z = 1.0f, m.zz = 1.0f, m.xz = xv.x, m.yz = yf;
+                } else if (HASZ) {
+                    m.xz = __fmul_rn(xv.x, zf);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) a[d] = HASZ ? poly_a<true>(b2, d, m) : poly_a<false>(b2, d, Monomials<false>{m.x, m.y, 0.0f, m.xx, m.yy, 0.0f, m.xy, 0.0f, 0.0f});
+            }
+            float fx, fy, w0;
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(a[0], vol, 0), vol.hx1), hl.xhi, fx, w0, q.wx1);
+            axis_taps_halo(unnormalise(normalise_axis<FAST>(a[1], vol, 1), vol.hy1), hl.yhi, fy, w0, q.wy1);
+            const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);   // base corner, slice 0
+            unsigned zo = 0u;
+            if (HASZ) {
+                const float uz = unnormalise(normalise_axis<FAST>(a[2], vol, 2), vol.hz1);
+                if (ZM == 2) {
+                    // the pair is (0, 1).  With f = floor(u) the reference's weights are u - f and (f + 1) - u (axis_weights);
+                    // member 0 is tap f + 1 for u in [-1, 0) (weight u + 1) and tap f for u in [0, 1) (weight 1 - u), member 1
+                    // tap f + 1 for u in [0, 1) (weight u) and tap f for u in [1, 2) (weight 2 - u): the same fp32 operations
+                    // on the same operands, picked by one v_med3 each (the smaller of two expressions while both are
+                    // positive, 0 once one is not); NaN and far-away coordinates are pulled to -2 / 3, where both are 0.
+                    // d weight / d u of member 0 is +1 for f = -1 and -1 for f = 0, of member 1 +1 for f = 0 and -1 for
+                    // f = 1, else 0: with c = 2 f + 1 (c - 2) that is -c where |c| = 1.
+                    const float uc = __builtin_amdgcn_fmed3f(uz, -2.0f, 3.0f);
+                    q.wzm[0] = __builtin_amdgcn_fmed3f(0.0f, __fadd_rn(uc, 1.0f), __fsub_rn(1.0f, uc));
+                    q.wzm[1] = __builtin_amdgcn_fmed3f(0.0f, uc, __fsub_rn(2.0f, uc));
+                    const float c0 = fmaf(2.0f, floorf(uc), 1.0f), c1 = c0 - 2.0f;
+                    q.vz[0] = fabsf(c0) == 1.0f ? -c0 : 0.0f;
+                    q.vz[1] = fabsf(c1) == 1.0f ? -c1 : 0.0f;
+                } else {
+                    int iz;
+                    float wz[2];
+                    axis_weights(uz, iz, wz[0], wz[1]);
+                    // member 0 / 1 of the pair (izc, izc + 1) stands for tap iz / iz + 1 when iz == izc, member 0 for tap
+                    // iz + 1 when iz == izc - 1 (tap iz = -1 is outside), member 1 for tap iz when iz == izc + 1 (tap
+                    // iz + 1 = Z is outside); vz = d weight / d u_z of the tap a member stands for
+                    const int izc = clamp_index(iz, vol.Z - 1);
+                    const bool same = iz == izc, below = iz + 1 == izc, above = iz == izc + 1;
+                    q.wzm[0] = same ? wz[0] : (below ? wz[1] : 0.0f);
+                    q.wzm[1] = same ? wz[1] : (above ? wz[0] : 0.0f);
+                    q.vz[0] = same ? -1.0f : (below ? 1.0f : 0.0f);
+                    q.vz[1] = same ? 1.0f : (above ? -1.0f : 0.0f);
+                    zo = (unsigned)izc * 4u;
+                }
+            }
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                unsigned o = o0 + (ZM == 3 ? zo : 0u) + (dx ? (unsigned)hl.row4 : 0u);   // (scalar base + 32-bit offset) loads
+                asm("" : "+v"(o));
+                const char *t = s + o;
+                if constexpr (ZM == 2) {          // (y, z0), (y, z1), (y + 1, z0), (y + 1, z1): one load, 8-byte aligned
+                    const f32x4_a8 v = *reinterpret_cast<const f32x4_a8 *>(t);
+                    q.sv[0][0][dx] = v.x, q.sv[1][0][dx] = v.y, q.sv[0][1][dx] = v.z, q.sv[1][1][dx] = v.w;
+                } else if constexpr (ZM == 3) {   // the z-pair of corner y, then of corner y + 1
+                    const f32x2_a4 v0 = *reinterpret_cast<const f32x2_a4 *>(t);
+                    const f32x2_a4 v1 = *reinterpret_cast<const f32x2_a4 *>(t + hl.col4);
+                    q.sv[0][0][dx] = v0.x, q.sv[1][0][dx] = v0.y, q.sv[0][1][dx] = v1.x, q.sv[1][1][dx] = v1.y;
+                } else {
+                    q.sv[0][0][dx] = *reinterpret_cast<const float *>(t);
+                    q.sv[0][1][dx] = *reinterpret_cast<const float *>(t + 4);
+                }
+            }
+        };
         auto request = [&](int x, Req &q) {
             q.xv = xtab[x];                   // a scalar load
             q.prow = (long)x * YZ;            // block-uniform: (scalar base + 32-bit lane offset) accesses
-            Monomials<HASZ> m = mono;
-            m.x = q.xv.x, m.xx = q.xv.y, m.xy = __fmul_rn(q.xv.x, yf);
-            if (HASZ) m.xz = __fmul_rn(q.xv.x, zf);
-            float fx, fy;
-            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 0, m), vol, 0), vol.hx1), hl.xhi, fx, q.wx[0],
-                           q.wx[1]);
-            axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 1, m), vol, 1), vol.hy1), hl.yhi, fy, q.wy[0],
-                           q.wy[1]);
-            const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);   // base corner, slice 0
-            int iz = 0;
-            if (HASZ) {
-                float wz[2];
-                axis_weights(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1), iz, wz[0], wz[1]);
-#pragma unroll
-                for (int dz = 0; dz < 2; ++dz) {
-                    const bool zin = in_range(iz + dz, vol.Z);
-                    q.wzm[dz] = zin ? wz[dz] : 0.0f;
-                    q.vz[dz] = zin ? (dz ? 1.0f : -1.0f) : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-                const unsigned zo = HASZ ? (unsigned)clamp_index(iz + dz, vol.Z) * 4u : 0u;
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    unsigned o = o0 + zo + (dx ? (unsigned)hl.row4 : 0u);   // (scalar base + 32-bit offset) loads
-                    asm("" : "+v"(o));
-                    const char *t = s + o;
-                    q.sv[dz][0][dx] = *reinterpret_cast<const float *>(t);
-                    q.sv[dz][1][dx] = *reinterpret_cast<const float *>(t + (HASZ ? hl.col4 : 4));
-                }
-            }
+            const float xy = __fmul_rn(q.xv.x, yf);
             asm("" : "+v"(u4));
-            q.other = *reinterpret_cast<const float *>(reinterpret_cast<const char *>((!PLAIN && go ? go : y) + q.prow) + u4);
+            const char *op = reinterpret_cast<const char *>((!PLAIN && go ? go : y) + q.prow) + u4;
+            if constexpr (ZPAIR) {
+                taps(q.xv, xy, std::integral_constant<int, 0>{}, q.v[0]);
+                taps(q.xv, xy, std::integral_constant<int, 1>{}, q.v[1]);
+                const float2 o2 = *reinterpret_cast<const float2 *>(op);   // (x, y, 0), (x, y, 1): eight aligned bytes
+                q.v[0].other = o2.x, q.v[NV - 1].other = o2.y;
+            } else {
+                taps(q.xv, xy, std::integral_constant<int, -1>{}, q.v[0]);
+                q.v[0].other = *reinterpret_cast<const float *>(op);
+            }
         };
-        auto consume = [&](const Req &q) {
-            float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
+        auto consume = [&](const Req &rq) {
+            float recs[NV];
 #pragma unroll
-            for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
-                const float a0 = fmaf(q.wx[1], q.sv[dz][0][1], q.wx[0] * q.sv[dz][0][0]);  // x-interpolated rows y0, y1
-                const float a1 = fmaf(q.wx[1], q.sv[dz][1][1], q.wx[0] * q.sv[dz][1][0]);
-                const float d0 = q.sv[dz][0][1] - q.sv[dz][0][0];                          // x-differences of the rows
-                const float d1 = q.sv[dz][1][1] - q.sv[dz][1][0];
-                const float r2 = fmaf(q.wy[1], a1, q.wy[0] * a0);                          // value of this z-slice
-                const float gx2 = fmaf(q.wy[1], d1, q.wy[0] * d0);
-                const float gy2 = a1 - a0;
-                if (HASZ) {
-                    rec = fmaf(q.wzm[dz], r2, rec);
-                    g[0] = fmaf(q.wzm[dz], gx2, g[0]);
-                    g[1] = fmaf(q.wzm[dz], gy2, g[1]);
-                    g[2] = fmaf(q.vz[dz], r2, g[2]);
-                } else {
-                    rec = r2, g[0] = gx2, g[1] = gy2;
+            for (int v = 0; v < NV; ++v) {
+                const Vox &q = rq.v[v];
+                float rec = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int dz = 0; dz < (HASZ ? 2 : 1); ++dz) {
+                    // x- and y-blends as s0 + w1 (s1 - s0): the weights of an axis add up to exactly 1 (u - f and
+                    // (f + 1) - u are exact), the differences are the gradient's anyway -- one operation less per blend
+                    // than w0 s0 + w1 s1
+                    const float d0 = q.sv[dz][0][1] - q.sv[dz][0][0];                          // x-differences of the rows
+                    const float d1 = q.sv[dz][1][1] - q.sv[dz][1][0];
+                    const float a0 = fmaf(q.wx1, d0, q.sv[dz][0][0]);                          // x-interpolated rows y0, y1
+                    const float a1 = fmaf(q.wx1, d1, q.sv[dz][1][0]);
+                    const float gy2 = a1 - a0;
+                    const float r2 = fmaf(q.wy1, gy2, a0);                                     // value of this z-slice
+                    const float gx2 = fmaf(q.wy1, d1 - d0, d0);
+                    if (HASZ) {
+                        rec = fmaf(q.wzm[dz], r2, rec);
+                        g[0] = fmaf(q.wzm[dz], gx2, g[0]);
+                        g[1] = fmaf(q.wzm[dz], gy2, g[1]);
+                        g[2] = fmaf(q.vz[dz], r2, g[2]);
+                    } else {
+                        rec = r2, g[0] = gx2, g[1] = gy2;
+                    }
+                }
+                recs[v] = rec;
+                // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
+                const float resid = !PLAIN && go ? q.other : rec - q.other;
+                sq = fmaf(resid, resid, sq);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const float gd = resid * g[d];
+                    mom[v][0][d] += gd;
+                    mom[v][1][d] = fmaf(rq.xv.x, gd, mom[v][1][d]);
+                    mom[v][2][d] = fmaf(rq.xv.y, gd, mom[v][2][d]);
                 }
             }
-            if (!PLAIN && rc) *reinterpret_cast<float *>(reinterpret_cast<char *>(rc + q.prow) + u4) = rec;
-            // upstream gradient: the mse residual (scaled by 2/(B P) in the finish kernel) or the caller's
-            const float resid = !PLAIN && go ? q.other : rec - q.other;
-            sq = fmaf(resid, resid, sq);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const float gd = resid * g[d];
-                mom[0][d] += gd;
-                mom[1][d] = fmaf(q.xv.x, gd, mom[1][d]);
-                mom[2][d] = fmaf(q.xv.y, gd, mom[2][d]);
+            if (!PLAIN && rc) {
+                char *dst = reinterpret_cast<char *>(rc + rq.prow) + u4;
+                if constexpr (ZPAIR)
+                    *reinterpret_cast<float2 *>(dst) = make_float2(recs[0], recs[NV - 1]);
+                else
+                    *reinterpret_cast<float *>(dst) = recs[0];
             }
         };
         if (nrow == K2_ROWS) {
             // K2_UNROLL rows at a time: their taps are requested together, then blended (keeping the next rows' taps in
             // flight behind the blends of the current ones did not pay: 2.07 against 1.99 ms, tools/time_k2.py)
+            constexpr int UR = HASZ ? K2_UNROLL_Z : K2_UNROLL;
 #pragma unroll 1
-            for (int i = 0; i < K2_ROWS; i += K2_UNROLL) {
-                Req q[K2_UNROLL];
+            for (int i = 0; i < K2_ROWS; i += UR) {
+                Req q[UR];
 #pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) request(x_first + i + j, q[j]);
+                for (int j = 0; j < UR; ++j) request(x_first + i + j, q[j]);
 #pragma unroll
-                for (int j = 0; j < K2_UNROLL; ++j) consume(q[j]);
+                for (int j = 0; j < UR; ++j) consume(q[j]);
             }
         } else {
             for (int i = 0; i < nrow; ++i) {
@@ -188,15 +288,23 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     float acc[NA][ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        acc[0][d] = mom[0][d], acc[1][d] = mom[1][d], acc[2][d] = yf * mom[0][d], acc[3][d] = mom[2][d];
-        acc[4][d] = (yf * yf) * mom[0][d], acc[5][d] = yf * mom[1][d];
+        // Z == 2: the z-free terms sum both slices, the terms with z are slice 1's (z = 1; slice 0 contributes zeros)
+        const float m0 = ZPAIR ? mom[0][0][d] + mom[NV - 1][0][d] : mom[0][0][d];
+        const float m1 = ZPAIR ? mom[0][1][d] + mom[NV - 1][1][d] : mom[0][1][d];
+        const float m2 = ZPAIR ? mom[0][2][d] + mom[NV - 1][2][d] : mom[0][2][d];
+        acc[0][d] = m0, acc[1][d] = m1, acc[2][d] = yf * m0, acc[3][d] = m2;
+        acc[4][d] = (yf * yf) * m0, acc[5][d] = yf * m1;
         if (HASZ) {
-            acc[6][d] = zf * mom[0][d], acc[7][d] = (zf * zf) * mom[0][d], acc[8][d] = zf * mom[1][d];
-            acc[9][d] = (yf * zf) * mom[0][d];
+            const float z0 = mom[NV - 1][0][d], z1 = mom[NV - 1][1][d];
+            const float zz = ZPAIR ? 1.0f : zf;
+            acc[6][d] = zz * z0, acc[7][d] = (zz * zz) * z0, acc[8][d] = zz * z1;
+            acc[9][d] = (yf * zz) * z0;
         }
     }
 
-    // block reduction: butterflies inside each wave, then the four wave leaders through LDS
+    // block reduction: a DPP tree inside each wave (six vector adds per sum, total in lane 63; the butterflies of
+    // __shfl_xor it replaces are LDS permutes with an address computation each -- 31 sums x 6 steps per 16 rows were
+    // a fifth of the kernel's instructions), then the four waves' totals through LDS
     __shared__ float red[4][K2_NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < K2_NACC) red[wave][lane] = 0.0f;
@@ -205,12 +313,12 @@ __global__ __launch_bounds__(256) void warp_recon_grad_kernel(const float *__res
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const float v = wave_sum(acc[a][d]);
-            if (lane == 0) red[wave][BASIS_ID[a] * 3 + d] = v;
+            const float v = wave_sum_last(acc[a][d]);
+            if (lane == 63) red[wave][BASIS_ID[a] * 3 + d] = v;
         }
     {
-        const float v = wave_sum(sq);
-        if (lane == 0) red[wave][30] = v;
+        const float v = wave_sum_last(sq);
+        if (lane == 63) red[wave][30] = v;
     }
     __syncthreads();
     if (threadIdx.x < K2_NACC) {
@@ -294,7 +402,7 @@ __global__ __launch_bounds__(64) void sum_loss_kernel(const float *__restrict__ 
 extern "C" {
 
 static long k2_blocks(int X, int Y, int Z, int *nub_out) {
-    const long nub = ((long)Y * Z + dnmf::K2_COLS - 1) / dnmf::K2_COLS;
+    const long nub = ((long)Y * (Z == 2 ? 1 : Z) + dnmf::K2_COLS - 1) / dnmf::K2_COLS;   // Z == 2: a lane owns both slices
     if (nub_out) *nub_out = (int)nub;
     return nub * ((X + dnmf::K2_ROWS - 1) / dnmf::K2_ROWS);
 }
@@ -332,10 +440,12 @@ static void k2_launch_main(const float *S, long lds, const int *s_ids, const flo
     else if (vol.fastdiv) DNMF_K2_LAUNCH(HZ, 1, false, PL);         \
     else DNMF_K2_LAUNCH(HZ, 0, false, PL)
     const bool plain = frames && !gout && !recon;
-    if (vol.Z > 1) {
-        if (plain) { DNMF_K2_VARIANTS(true, true); } else { DNMF_K2_VARIANTS(true, false); }
+    if (vol.Z > 2) {
+        if (plain) { DNMF_K2_VARIANTS(3, true); } else { DNMF_K2_VARIANTS(3, false); }
+    } else if (vol.Z == 2) {
+        if (plain) { DNMF_K2_VARIANTS(2, true); } else { DNMF_K2_VARIANTS(2, false); }
     } else {
-        if (plain) { DNMF_K2_VARIANTS(false, true); } else { DNMF_K2_VARIANTS(false, false); }
+        if (plain) { DNMF_K2_VARIANTS(1, true); } else { DNMF_K2_VARIANTS(1, false); }
     }
 #undef DNMF_K2_VARIANTS
 #undef DNMF_K2_LAUNCH

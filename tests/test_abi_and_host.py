@@ -76,7 +76,7 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert lib.dnmf_mu_temporal_nbr(addr, addr, addr, 4, 3, 4, 1, addr, 12, None) == -3                   # NN not 8/16/32
     assert lib.dnmf_adam_epoch_workspace(1000) == 16000
     assert lib.dnmf_adam_epoch(addr, None, addr, addr, 4, 0, addr, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0, addr, 8, None) == -4
-    assert lib.dnmf_warp_recon_grad_workspace(512, 512, 1, 4000) == 512 * 8 + 4000 * 64 * 32 * 4 + 4000 * 4
+    assert lib.dnmf_warp_recon_grad_workspace(512, 512, 1, 4000) == 512 * 8 + 4000 * 32 * 32 * 4 + 4000 * 4
     # C1: arguments are checked before RCCL is looked up
     assert lib.dnmf_comm_unique_id(None) == -1
     assert lib.dnmf_comm_init(None, addr, 2, 0) == -1
