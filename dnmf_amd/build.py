@@ -17,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdnmf_hip.so")
-SOURCES = ["api_common.hip", "warp_gather.hip", "recon_image.hip", "warp_recon_grad.hip", "warp_gram_rhs.hip", "warp_gram_sparse.hip", "warp_gram_lists.hip", "recon_lists.hip",
+SOURCES = ["api_common.hip", "warp_gather.hip", "recon_image.hip", "warp_recon_grad.hip", "warp_gram_rhs.hip", "warp_gram_sparse.hip", "warp_gram_lists.hip", "warp_gram_lists_z.hip", "recon_lists.hip",
            "mu_temporal.hip", "render_frames.hip", "adam_epoch.hip", "spatial_update.hip", "image_iwarp.hip", "collective.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
@@ -31,6 +31,8 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# sources that include another source
+EXTRA_DEPS = {"warp_gram_lists_z.hip": ["warp_gram_lists.hip"]}
 # what the last build_library() call did: "compiled" or "reused" (the library was newer than every source)
 LAST_ACTION = None
 # flags of single files (measured per kernel)
@@ -38,6 +40,9 @@ PER_FILE_FLAGS = {
     # K2: the SLP vectoriser's packed fp32 operations issue no faster than two scalar ones and cost register shuffles
     # (512x512x2x4000: 6.55 ms against 6.93; Z == 1 unchanged)
     "warp_recon_grad.hip": ["-fno-slp-vectorize"],
+    # K3n for Z >= 2: packed operations want their operands in register pairs -- 200 registers instead of 150, spills
+    # (512x512x2x4000: 19.9 ms against 6.6); the Z == 1 instantiations (warp_gram_lists.hip) keep the vectoriser
+    "warp_gram_lists_z.hip": ["-fno-slp-vectorize"],
 }
 
 
@@ -77,7 +82,8 @@ def build_library(force: bool = False, verbose: bool = True, out: str | None = N
         extra = [*PER_FILE_FLAGS.get(s, []), *(defines if (only is None or s in only) else [])]
         src, obj = os.path.join(CSRC, s), os.path.join(objdir_for(extra), s + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+        dep_time = max([os.path.getmtime(src), hdr_time, *[os.path.getmtime(os.path.join(CSRC, d)) for d in EXTRA_DEPS.get(s, [])]])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_time:
             jobs.append(([hipcc, *cflags, *extra, "-c", src, "-o", obj], s))
     if verbose:
         print(f"[dnmf_amd.build] {hipcc} {' '.join([*cflags, *defines])}: compiling {[j[1] for j in jobs]}, "

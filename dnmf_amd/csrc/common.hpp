@@ -251,6 +251,20 @@ __device__ __forceinline__ unsigned halo_offset(float fx, float fy, const HaloLa
     return (unsigned)(__mul24((int)fx, h.row4) + __mul24((int)fy, h.col4)) + origin;
 }
 
+// Z == 2: the two z-taps of a corner are the adjacent floats (slice 0, slice 1) of a halo row and are fetched as that
+// pair.  With f = floor(u) the reference's weights are u - f for tap f + 1 and (f + 1) - u for tap f (axis_weights), and a
+// tap outside [0, Z) is dropped (grid_sample's per-corner bounds test).  Slice 0 is tap f + 1 for u in [-1, 0) (weight
+// u + 1) and tap f for u in [0, 1) (weight 1 - u); slice 1 is tap f + 1 for u in [0, 1) (weight u) and tap f for u in
+// [1, 2) (weight 2 - u): the same fp32 operations on the same operands, picked by one v_med3 each (the smaller of the two
+// expressions while both are positive, 0 once one is not).  NaN and far-away coordinates are pulled to -2 / 3 first,
+// where both weights are 0.  Returns the clamped coordinate.
+__device__ __forceinline__ float z_pair_weights(float uz, float &w0, float &w1) {
+    const float uc = __builtin_amdgcn_fmed3f(uz, -2.0f, 3.0f);
+    w0 = __builtin_amdgcn_fmed3f(0.0f, __fadd_rn(uc, 1.0f), __fsub_rn(1.0f, uc));
+    w1 = __builtin_amdgcn_fmed3f(0.0f, uc, __fsub_rn(2.0f, uc));
+    return uc;
+}
+
 __device__ __forceinline__ bool in_range(int i, int n) { return (unsigned)i < (unsigned)n; }
 
 // The NTAP = 4 (Z == 1) or 8 gather taps of a sample, corner order of ATen's grid_sampler (dx fastest, then dy,

@@ -47,6 +47,8 @@
 namespace dnmf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // four floats at an 8-byte aligned address
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 #ifndef DNMF_K3N_NT
 #define DNMF_K3N_NT 0   // frame values by non-temporal loads
@@ -68,6 +70,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef DNMF_K3N_WAVES
 #define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
+#endif
+#ifndef DNMF_K3N_WAVES_Z2
+#define DNMF_K3N_WAVES_Z2 4   // the same for Z == 2
+#endif
+#ifndef DNMF_K3N_WAVES_Z2L
+#define DNMF_K3N_WAVES_Z2L 3  // its long-list pass (two groups of four neurons' values in registers)
+#endif
+#ifndef DNMF_K3N_WAVES_Z3
+#define DNMF_K3N_WAVES_Z3 3   // and for Z > 2 (direct gathers only)
 #endif
 
 constexpr int LISTS_NG = 4;      // neurons evaluated together (register slots); longer lists are cut into groups
@@ -126,6 +137,7 @@ __host__ __device__ inline long axis_masks_offset(const Volume &vol, int d, int 
 }
 __host__ __device__ inline long axis_masks_entries(const Volume &vol) { return 2L * (vol.X + vol.Y + vol.Z + 6); }
 
+#ifndef DNMF_K3N_TU_Z   // (the translation unit of the Z >= 2 instantiations takes only the templates)
 __global__ __launch_bounds__(256) void lists_axis_masks_kernel(const int *__restrict__ bbox, int K, Volume vol, int NW,
                                                                unsigned long long *__restrict__ masks) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -148,6 +160,8 @@ __global__ __launch_bounds__(256) void lists_axis_masks_kernel(const int *__rest
         masks[e * NW + w] = m;
     }
 }
+
+#endif  // DNMF_K3N_TU_Z
 
 // One thread per (frame, tile): the tile's neuron list as NW 64-bit words.
 template <int NW>
@@ -192,11 +206,14 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
     for (int w = 0; w < NW; ++w) p.tile_masks[id * NW + w] = m[w];
     // the region of a footprint image that holds every tap of the tile (the gathers clamp their base corner into
     // [-HALO, S], the second corner is one further), origin pulled back so that the region stays inside the image
+    // (Z == 2: a halo row interleaves the two slices, column y of the volume is floats 2 (y + HALO), 2 (y + HALO) + 1, and
+    // the region holds both slices of its columns, so the z range of the taps does not matter)
     int2 reg = make_int2(-1, 0);
-    if (!hasz && finite && p.hl.Xp >= LISTS_RR && p.hl.rowf >= LISTS_RC && p.hl.Xp < 32768 && p.hl.rowf < 65536) {
+    if (vol.Z <= 2 && finite && p.hl.Xp >= LISTS_RR && p.hl.rowf >= LISTS_RC && p.hl.Xp < 32768 && p.hl.rowf < 65536) {
         const int ax = max(ta[0], -HALO), cx = min(tc[0], vol.X + 1), ay = max(ta[1], -HALO), cy = min(tc[1], vol.Y + 1);
-        const int r0 = min(ax + HALO, p.hl.Xp - LISTS_RR), c0 = min((ay + HALO) & ~3, p.hl.rowf - LISTS_RC);
-        if (cx >= ax && cy >= ay && cx + HALO - r0 < LISTS_RR && cy + HALO - c0 < LISTS_RC) reg = make_int2(r0, c0);
+        const int r0 = min(ax + HALO, p.hl.Xp - LISTS_RR), c0 = min(((ay + HALO) * vol.Z) & ~3, p.hl.rowf - LISTS_RC);
+        if (cx >= ax && cy >= ay && cx + HALO - r0 < LISTS_RR && (cy + HALO) * vol.Z + vol.Z - 1 - c0 < LISTS_RC)
+            reg = make_int2(r0, c0);
     }
     int nlist = 0;
     unsigned ids = 0xffffffffu;
@@ -219,11 +236,18 @@ __global__ __launch_bounds__(256) void lists_tilemask_kernel(ListParams p) {
 // of all paths of one: with the staged long-list code inside, the short-list loop spilled.  PASS 0 is the one-kernel
 // form (every tile, long lists by direct gathers) for launches whose waves have only a short run of tiles each, where the
 // second launch costs more than it saves; the host picks (lists_passes).
-template <int NTAP, int NW, int FAST, bool F32OFF, int PASS>
-__global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gram_lists_kernel(ListParams p) {
+//
+// ZM = 1: Z == 1 (four taps).  ZM = 2: Z == 2 -- the two z-taps of a corner are the adjacent floats of a halo row, fetched
+// as the pair (slice 0, slice 1) whose members take the weight of the tap they stand for (warp_recon_grad.hip has the
+// derivation), from the staged region like Z == 1 (a region is 12 rows x 20 columns x 2 slices) or, for tiles without a
+// region, as two sixteen-byte gathers per voxel and neuron.  ZM = 3: Z > 2, four eight-byte gathers (z-pair of a corner).
+// For Z >= 2 the blend is hierarchical (z, then y, then x: s0 + w1 (s1 - s0) along x and y, whose weights add up to 1
+// exactly) from four weights per voxel; eight pre-multiplied weights per voxel cost 16 more registers.
+template <int ZM, int NW, int FAST, bool F32OFF, int PASS>
+__global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS == 2 ? DNMF_K3N_WAVES_Z2L : DNMF_K3N_WAVES_Z2) : DNMF_K3N_WAVES_Z3))) void warp_gram_lists_kernel(ListParams p) {
     constexpr bool LONGPASS = PASS == 2;
     extern __shared__ float s_tab[];
-    constexpr bool HASZ = NTAP == 8;
+    constexpr bool HASZ = ZM > 1;
     constexpr int NPAIR = LISTS_NG * (LISTS_NG + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
               }
           }
           const int4 dsc = descs[ql];
-          my_reg = HASZ ? -1 : dsc.x, my_ids = dsc.y, my_n = dsc.z, my_place = dsc.w;
+          my_reg = ZM == 3 ? -1 : dsc.x, my_ids = dsc.y, my_n = dsc.z, my_place = dsc.w;
       }
       if (LONGPASS) {   // nothing for this pass among these 64 tiles?
           int myn = 0;
@@ -444,14 +468,14 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
         const bool yz_in = y < vol.Y && z < vol.Z;
         // staged gathers for this tile?  (wave-uniform)
         int reg_r0 = -1, reg_c0 = 0;
-        if (!HASZ) {
+        if (ZM != 3) {
             const int rg = __builtin_amdgcn_readlane(my_reg, jl);
             reg_r0 = rg < 0 ? -1 : rg >> 16, reg_c0 = rg & 0xffff;
         }
         // lists of more than two groups keep the direct gathers (and their offsets)
-        const bool staged = !HASZ && reg_r0 >= 0 && n <= (PASS == 2 ? 2 : 1) * LISTS_NG;
-        // byte offset of volume voxel (0,0) inside a staged region, and of the region inside a footprint image
-        const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO - reg_c0);
+        const bool staged = ZM != 3 && reg_r0 >= 0 && n <= (PASS == 2 ? 2 : 1) * LISTS_NG;
+        // byte offset of volume voxel (0,0,0) inside a staged region, and of the region inside a footprint image
+        const float lds_origin = 4.0f * (float)((HALO - reg_r0) * LISTS_RC + HALO * (ZM == 2 ? 2 : 1) - reg_c0);
         const unsigned reg_goff = (unsigned)(reg_r0 * hl.row4 + reg_c0 * 4);
 
         // staged: the region of neuron k into staging slot i (two sixteen-byte pieces per lane, 120 in all) ...
@@ -470,21 +494,23 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             *reinterpret_cast<f32x4 *>(dst + lane * 16) = piece[0];
             if (lane + 64 < LISTS_REGION / 4) *reinterpret_cast<f32x4 *>(dst + (lane + 64) * 16) = piece[1];
         };
-#if DNMF_K3N_EARLY1
         // The region of the list's first neuron is requested here, ahead of the coordinate arithmetic, which hides its
         // latency (3.10 -> 3.05 ms per 4000 frames at 512x512, K=100).  Eight registers in flight fit; the first TWO
-        // neurons' regions (sixteen) spill: 3.98 ms.
+        // neurons' regions (sixteen) spill: 3.98 ms.  Z == 1 only: with the third coordinate chain of Z == 2 in flight the
+        // eight registers are not there (151 registers wanted against 131 without).
+        constexpr bool EARLY = DNMF_K3N_EARLY1 && PASS == 1 && ZM == 1;
         f32x4 early[2];
-        if (PASS == 1 && staged) {
+        if (EARLY && staged) {
             stage_load((int)((unsigned)ids & 0xffu), early);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
 
         // ---- taps of this lane's four voxels: byte offsets of the two x-columns of the tap cell, weights ------------
-        unsigned off[LISTS_VPL][NTAP / 2];   // [.][dx + 2 dz]: the (y, y+1) pair is one eight-byte load; a staged tile
-                                             // keeps the LDS byte offset of the base corner inside a region in [.][0]
-        float w[LISTS_VPL][NTAP];            // [.][dy + 2 (dx + 2 dz)]
+        // Z == 1: off[.][dx] = byte offset of the (y, y+1) pair of x-column dx, w[.][dy + 2 dx] the four weights.
+        // Z >= 2: off[.][0] = byte offset of the base corner's z-pair, w[.] = {weight of x-corner 1, of y-corner 1,
+        // of the z-pair's members}.  A staged tile keeps the LDS byte offset of the base corner inside a region in off[.][0].
+        unsigned off[LISTS_VPL][HASZ ? 1 : 2];
+        float w[LISTS_VPL][4];
         float yv[LISTS_VPL];
         const int xt = qx << (lgx + LISTS_LGV);  // first x of the tile
         const float x0f = (float)(xt + lx);
@@ -505,6 +531,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                 for (int d = 0; d < (HASZ ? 3 : 2); ++d) ud[d] = fmaf(xf, fmaf(xf, hc2[d], hc1[d]), hc0[d]);
                 axis_taps_halo(ud[0], hl.xhi, fx, wx[0], wx[1]);
                 axis_taps_halo(ud[1], hl.yhi, fy, wy[0], wy[1]);
+                const float uz = HASZ ? ud[2] : 0.0f;
 #else
                 Monomials<HASZ> m = mono;
                 m.x = x0f + (float)(v << lgx), m.xx = __fmul_rn(m.x, m.x), m.xy = __fmul_rn(m.x, m.y);
@@ -513,38 +540,39 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                                wx[1]);
                 axis_taps_halo(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 1, m), vol, 1), vol.hy1), hl.yhi, fy, wy[0],
                                wy[1]);
+                const float uz = HASZ ? unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1) : 0.0f;
 #endif
                 const unsigned o0 = halo_offset<F32OFF>(fx, fy, hl, hl.origin4, hl.origin4f);
-                float wzm[2] = {1.0f, 0.0f};
-                unsigned zo[2] = {0u, 0u};
-                if (HASZ) {
-                    int iz;
-                    float wz[2];
-#if DNMF_K3N_DIRECT
-                    axis_weights(ud[2], iz, wz[0], wz[1]);
-#else
-                    axis_weights(unnormalise(normalise_axis<FAST>(poly_a<HASZ>(b2, 2, m), vol, 2), vol.hz1), iz, wz[0], wz[1]);
-#endif
-#pragma unroll
-                    for (int dz = 0; dz < 2; ++dz) {
-                        wzm[dz] = in_range(iz + dz, vol.Z) ? wz[dz] : 0.0f;
-                        zo[dz] = (unsigned)clamp_index(iz + dz, vol.Z) * 4u;
-                    }
-                }
                 const bool in = FULL || (yz_in && x < vol.X);   // a voxel beyond the volume: weights 0, frame value 0
-#pragma unroll
-                for (int dz = 0; dz < NTAP / 4; ++dz)
+                if constexpr (HASZ) {
+                    float wzm[2];
+                    unsigned zo = 0u;
+                    if (ZM == 2) {   // the pair (0, 1): common.hpp, z_pair_weights
+                        z_pair_weights(uz, wzm[0], wzm[1]);
+                    } else {
+                        int iz;
+                        float wz[2];
+                        axis_weights(uz, iz, wz[0], wz[1]);
+                        const int izc = clamp_index(iz, vol.Z - 1);   // the pair (izc, izc + 1) inside the volume
+                        const bool same = iz == izc;
+                        wzm[0] = same ? wz[0] : (iz + 1 == izc ? wz[1] : 0.0f);
+                        wzm[1] = same ? wz[1] : (iz == izc + 1 ? wz[0] : 0.0f);
+                        zo = (unsigned)izc * 4u;
+                    }
+                    // (a voxel beyond the volume is not covered by the tile's region: it reads the region's first floats,
+                    // times zero)
+                    off[v][0] = staged ? (in ? (unsigned)fmaf(fx, (float)(4 * LISTS_RC), fmaf(fy, 8.0f, lds_origin)) : 0u) : o0 + zo;
+                    w[v][0] = wx[1], w[v][1] = wy[1], w[v][2] = in ? wzm[0] : 0.0f, w[v][3] = in ? wzm[1] : 0.0f;
+                } else {
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        off[v][dx + 2 * dz] = o0 + zo[dz] + (dx ? (unsigned)hl.row4 : 0u);
-                        // (a voxel beyond the volume is not covered by the tile's region: it reads the region's first
-                        // float, times zero)
-                        if (!HASZ && staged && dx == 0)
+                        off[v][dx] = o0 + (dx ? (unsigned)hl.row4 : 0u);
+                        if (staged && dx == 0)
                             off[v][0] = in ? (unsigned)fmaf(fx, (float)(4 * LISTS_RC), fmaf(fy, 4.0f, lds_origin)) : 0u;
-                        const float wxz = HASZ ? __fmul_rn(wx[dx], wzm[dz]) : wx[dx];
 #pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) w[v][dy + 2 * (dx + 2 * dz)] = in ? __fmul_rn(wxz, wy[dy]) : 0.0f;
+                        for (int dy = 0; dy < 2; ++dy) w[v][dy + 2 * dx] = in ? __fmul_rn(wx[dx], wy[dy]) : 0.0f;
                     }
+                }
                 unsigned yo = in ? yo0 + (unsigned)v * ystep : 0u;
                 asm("" : "+v"(yo));
 #ifdef DNMF_K3N_ABL_FRAME   // timing ablation: no frame loads
@@ -554,6 +582,9 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                 const float val = DNMF_K3N_NT ? __builtin_nontemporal_load(yp) : *yp;
 #endif
                 yv[v] = in ? val : 0.0f;
+#ifdef DNMF_K3N_TAPS_BARRIER
+                if (HASZ) __builtin_amdgcn_sched_barrier(0);   // one voxel's coordinate chains at a time (registers)
+#endif
             }
         };
         if (full)
@@ -562,24 +593,50 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
             taps(std::false_type{});
         DNMF_STAMP(2)   // coordinates, weights, frame loads issued
 
+        // z-pair members -> y -> x for Z >= 2: quad = the (y, z0), (y, z1), (y + 1, z0), (y + 1, z1) values of x-corner 0 / 1
+        auto blend8 = [&](const float (&q0)[4], const float (&q1)[4], const float (&wv)[4]) {
+            const float t00 = fmaf(wv[3], q0[1], wv[2] * q0[0]), t01 = fmaf(wv[3], q0[3], wv[2] * q0[2]);
+            const float t10 = fmaf(wv[3], q1[1], wv[2] * q1[0]), t11 = fmaf(wv[3], q1[3], wv[2] * q1[2]);
+            const float a0 = fmaf(wv[1], t01 - t00, t00), a1 = fmaf(wv[1], t11 - t10, t10);
+            return fmaf(wv[0], a1 - a0, a0);
+        };
         auto eval = [&](int k, float (&a)[LISTS_VPL]) {
             const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane;
 #pragma unroll
             for (int v = 0; v < LISTS_VPL; ++v) {
-                float s = 0.0f;
+                if constexpr (HASZ) {
+                    float q[2][4];
 #pragma unroll
-                for (int e = 0; e < NTAP / 2; ++e) {
-                    // the offsets are re-materialised as 32-bit values here so that the loads take the
-                    // (scalar base + 32-bit vector offset) form; hoisted out of the neuron loop they become 64-bit pairs
-                    unsigned o = off[v][e];
-                    asm("" : "+v"(o));
-                    const char *src = Ak + o;
-                    const float s0 = *reinterpret_cast<const float *>(src);
-                    const float s1 = *reinterpret_cast<const float *>(src + (HASZ ? hl.col4 : 4));
-                    s = fmaf(s0, w[v][2 * e], s);
-                    s = fmaf(s1, w[v][2 * e + 1], s);
+                    for (int dx = 0; dx < 2; ++dx) {
+                        unsigned o = off[v][0] + (dx ? (unsigned)hl.row4 : 0u);
+                        asm("" : "+v"(o));
+                        const char *src = Ak + o;
+                        if constexpr (ZM == 2) {
+                            const f32x4_a8 t = *reinterpret_cast<const f32x4_a8 *>(src);
+                            q[dx][0] = t.x, q[dx][1] = t.y, q[dx][2] = t.z, q[dx][3] = t.w;
+                        } else {
+                            const f32x2_a4 t0 = *reinterpret_cast<const f32x2_a4 *>(src);
+                            const f32x2_a4 t1 = *reinterpret_cast<const f32x2_a4 *>(src + hl.col4);
+                            q[dx][0] = t0.x, q[dx][1] = t0.y, q[dx][2] = t1.x, q[dx][3] = t1.y;
+                        }
+                    }
+                    a[v] = blend8(q[0], q[1], w[v]);
+                } else {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        // the offsets are re-materialised as 32-bit values here so that the loads take the
+                        // (scalar base + 32-bit vector offset) form; hoisted out of the neuron loop they become 64-bit pairs
+                        unsigned o = off[v][e];
+                        asm("" : "+v"(o));
+                        const char *src = Ak + o;
+                        const float s0 = *reinterpret_cast<const float *>(src);
+                        const float s1 = *reinterpret_cast<const float *>(src + 4);
+                        s = fmaf(s0, w[v][2 * e], s);
+                        s = fmaf(s1, w[v][2 * e + 1], s);
+                    }
+                    a[v] = s;
                 }
-                a[v] = s;
             }
         };
         // ... and the warped values of the lane's voxels from there
@@ -588,15 +645,26 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #pragma unroll
             for (int v = 0; v < LISTS_VPL; ++v) {
                 const char *src = src0 + off[v][0];
-                float s = 0.0f;
+                if constexpr (HASZ) {   // Z == 2: four eight-byte reads (the z-pairs of the corners)
+                    float q[2][4];
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const float s0 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC));
-                    const float s1 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC) + 4);
-                    s = fmaf(s0, w[v][2 * dx], s);
-                    s = fmaf(s1, w[v][2 * dx + 1], s);
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const float2 t0 = *reinterpret_cast<const float2 *>(src + dx * (4 * LISTS_RC));
+                        const float2 t1 = *reinterpret_cast<const float2 *>(src + dx * (4 * LISTS_RC) + 8);
+                        q[dx][0] = t0.x, q[dx][1] = t0.y, q[dx][2] = t1.x, q[dx][3] = t1.y;
+                    }
+                    a[v] = blend8(q[0], q[1], w[v]);
+                } else {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const float s0 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC));
+                        const float s1 = *reinterpret_cast<const float *>(src + dx * (4 * LISTS_RC) + 4);
+                        s = fmaf(s0, w[v][2 * dx], s);
+                        s = fmaf(s1, w[v][2 * dx + 1], s);
+                    }
+                    a[v] = s;
                 }
-                a[v] = s;
             }
         };
         auto dot4 = [&](const float (&a)[LISTS_VPL], const float (&cc)[LISTS_VPL], float init) {
@@ -631,13 +699,10 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #ifndef DNMF_K3N_ABL_STAGE   // timing ablation: taps from whatever the LDS holds
 #pragma unroll
                         for (int i = i0; i < N && i < i0 + 2; ++i) {
-#if DNMF_K3N_EARLY1
-                            if (PASS == 1 && i == 0) {
+                            if (EARLY && i == 0) {
                                 piece[0][0] = early[0], piece[0][1] = early[1];
                                 continue;
                             }
-
-#endif
                             stage_load(ks[i], piece[i - i0]);
                         }
 #pragma unroll
@@ -649,10 +714,17 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
 #endif
                     DNMF_STAMP(3)   // regions requested, arrived (with the frame values), stored
 #pragma unroll
-                    for (int i = 0; i < N; ++i) eval_staged(i, a[i]);
+                    for (int i = 0; i < N; ++i) {
+                        eval_staged(i, a[i]);
+                        // Z >= 2: a neuron's taps are 32 values per lane; all four neurons' reads hoisted together spill
+                        if (HASZ) __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < N; ++i) eval(ks[i], a[i]);  // the rows of all N neurons are requested together
+                    for (int i = 0; i < N; ++i) {   // Z == 1: the rows of all N neurons are requested together
+                        eval(ks[i], a[i]);
+                        if (HASZ) __builtin_amdgcn_sched_barrier(0);   // (32 values per neuron and lane)
+                    }
                 }
                 int e = 0;
 #pragma unroll
@@ -703,7 +775,10 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
                 for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
             }
 #pragma unroll
-            for (int i = 0; i < LISTS_NG; ++i) eval_staged(i, aA[i]);
+            for (int i = 0; i < LISTS_NG; ++i) {
+                eval_staged(i, aA[i]);
+                if (HASZ) __builtin_amdgcn_sched_barrier(0);
+            }
             {
                 int e = 0;
 #pragma unroll
@@ -818,6 +893,7 @@ __global__ __launch_bounds__(256, (NTAP == 4 ? DNMF_K3N_WAVES : 2)) void warp_gr
     }
 }
 
+#ifndef DNMF_K3N_TU_Z
 // G[b] (K,K), r[b] (K) <- ordered sum of the chunk tables of frame b
 __global__ __launch_bounds__(256) void gram_lists_finish_kernel(const float *__restrict__ slab, int nchunks, int nslot,
                                                                 const int *__restrict__ pair_slot, int K,
@@ -972,17 +1048,26 @@ static int lists_passes(int chunk_len) {
     return chunk_len < 100 ? 1 : 2;
 }
 
+#endif  // DNMF_K3N_TU_Z
+
 // The stream the second pass runs on and the two events of its fork / join, one set per device, made on first use and
-// kept (the only state this file holds).
+// kept (the only state this file holds), with the mutex that serialises the fork / join of one device -- shared by every
+// instantiation and both translation units: the events are shared, and a wait takes whatever was last recorded on its
+// event when it is enqueued.
 struct SideStream {
+    std::mutex lock;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-static SideStream &side_stream() {
+SideStream &side_stream();   // locks nothing; callers hold .lock around the fork / join
+#ifndef DNMF_K3N_TU_Z
+SideStream &side_stream() {
     static SideStream per_device[64];
+    static std::mutex create;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     SideStream &ss = per_device[dev];
+    std::lock_guard<std::mutex> hold(create);
     if (!ss.stream) {
         hipStream_t s = nullptr;
         hipEvent_t a = nullptr, b = nullptr;
@@ -993,47 +1078,66 @@ static SideStream &side_stream() {
     }
     return ss;
 }
+#endif
 
-template <int NTAP, int NW, int FAST, bool F32OFF>
+template <int ZM, int NW, int FAST, bool F32OFF>
 static void launch_lists_passes(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
     if (p.tables == p.nchunks) {
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 0>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<ZM, NW, FAST, F32OFF, 0>), dim3(nwg), dim3(256), lds, st, p);
         return;
     }
     // fork: the second pass on the side stream behind the lists, join before anything that follows on `st`
-    // (one host thread at a time through the fork / join: the two events are shared, and a wait takes whatever was last
-    // recorded on its event when it is enqueued)
-    static std::mutex fork_join;
-    std::lock_guard<std::mutex> hold(fork_join);
+    // (one host thread at a time through the fork / join of a device)
     SideStream &ss = side_stream();
+    std::lock_guard<std::mutex> hold(ss.lock);
     const bool forked = ss.stream && hipEventRecord(ss.fork, st) == hipSuccess &&
                         hipStreamWaitEvent(ss.stream, ss.fork, 0) == hipSuccess;
     if (forked) {
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, ss.stream, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<ZM, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, ss.stream, p);
         const bool recorded = hipEventRecord(ss.join, ss.stream) == hipSuccess;
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<ZM, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
         if (!recorded || hipStreamWaitEvent(st, ss.join, 0) != hipSuccess)
             (void)hipStreamSynchronize(ss.stream);   // the join could not be enqueued: wait for the side stream here
     } else {   // no side stream to be had: one after the other
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
-        hipLaunchKernelGGL((warp_gram_lists_kernel<NTAP, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<ZM, NW, FAST, F32OFF, 1>), dim3(nwg), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((warp_gram_lists_kernel<ZM, NW, FAST, F32OFF, 2>), dim3(nwg), dim3(256), lds, st, p);
     }
 }
 
-template <int NTAP, int NW>
+template <int ZM, int NW>
 static void launch_lists_t(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st) {
     const long nthreads = (long)p.B * p.ntiles;
     hipLaunchKernelGGL((lists_tilemask_kernel<NW>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
     if (p.vol.fastdiv && p.hl.f32off)
-        launch_lists_passes<NTAP, NW, 1, true>(p, nwg, lds, st);
+        launch_lists_passes<ZM, NW, 1, true>(p, nwg, lds, st);
     else if (p.vol.fastdiv)
-        launch_lists_passes<NTAP, NW, 1, false>(p, nwg, lds, st);
+        launch_lists_passes<ZM, NW, 1, false>(p, nwg, lds, st);
     else
-        launch_lists_passes<NTAP, NW, 0, false>(p, nwg, lds, st);
+        launch_lists_passes<ZM, NW, 0, false>(p, nwg, lds, st);
 }
+
+// The Z >= 2 instantiations are compiled in warp_gram_lists_z.hip (this file again, under DNMF_K3N_TU_Z) with
+// -fno-slp-vectorize: the SLP vectoriser packs their blends into v_pk_* operations that need their operands in register
+// pairs, and the kernels then want 200 registers instead of 150 (19.9 ms per 4000 frames at 512x512x2 with the spills
+// against 6.6); the Z == 1 kernels, tuned with the vectoriser on, lose 15 % without it.
+void launch_lists_z(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st, int nw);
+#ifdef DNMF_K3N_TU_Z
+void launch_lists_z(const ListParams &p, unsigned nwg, size_t lds, hipStream_t st, int nw) {
+    if (p.vol.Z > 2) {
+        if (nw == 1) launch_lists_t<3, 1>(p, nwg, lds, st);
+        else if (nw == 2) launch_lists_t<3, 2>(p, nwg, lds, st);
+        else launch_lists_t<3, 4>(p, nwg, lds, st);
+    } else {
+        if (nw == 1) launch_lists_t<2, 1>(p, nwg, lds, st);
+        else if (nw == 2) launch_lists_t<2, 2>(p, nwg, lds, st);
+        else launch_lists_t<2, 4>(p, nwg, lds, st);
+    }
+}
+#endif
 
 }  // namespace dnmf
 
+#ifndef DNMF_K3N_TU_Z
 extern "C" {
 
 size_t dnmf_lists_axis_masks_bytes(int X, int Y, int Z, int K) {
@@ -1120,17 +1224,15 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
     const unsigned nwg = (unsigned)((nitems + 3) / 4);
     const int nw = lists_words(K);
     p.tile_desc = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.tile_masks) + lists_masks_bytes(K, B, p.ntiles));
-    // four slot tables (padded to 16 bytes), then for Z == 1 the four waves' staging regions
+    // four slot tables (padded to 16 bytes), then for Z <= 2 the four waves' staging regions
     const size_t lds = (((size_t)4 * nslot + 3) & ~(size_t)3) * sizeof(float) +
-                       (Z == 1 ? (size_t)4 * LISTS_NG * LISTS_REGION * sizeof(float) : 0);
+                       (Z <= 2 ? (size_t)4 * LISTS_NG * LISTS_REGION * sizeof(float) : 0);
     if (Z > 1) {
-        if (nw == 1) launch_lists_t<8, 1>(p, nwg, lds, st);
-        else if (nw == 2) launch_lists_t<8, 2>(p, nwg, lds, st);
-        else launch_lists_t<8, 4>(p, nwg, lds, st);
+        launch_lists_z(p, nwg, lds, st, nw);
     } else {
-        if (nw == 1) launch_lists_t<4, 1>(p, nwg, lds, st);
-        else if (nw == 2) launch_lists_t<4, 2>(p, nwg, lds, st);
-        else launch_lists_t<4, 4>(p, nwg, lds, st);
+        if (nw == 1) launch_lists_t<1, 1>(p, nwg, lds, st);
+        else if (nw == 2) launch_lists_t<1, 2>(p, nwg, lds, st);
+        else launch_lists_t<1, 4>(p, nwg, lds, st);
     }
     if (G)
         hipLaunchKernelGGL(gram_lists_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, p.slab, p.tables, nslot,
@@ -1149,3 +1251,4 @@ int dnmf_warp_gram_rhs_lists_chunks(int X, int Y, int Z, int B) {
 }
 
 }  // extern "C"
+#endif  // DNMF_K3N_TU_Z

@@ -154,16 +154,10 @@ __global__ __launch_bounds__(256, (ZM > 1 ? DNMF_K2_WAVES_Z : 1)) void warp_reco
             if (HASZ) {
                 const float uz = unnormalise(normalise_axis<FAST>(a[2], vol, 2), vol.hz1);
                 if (ZM == 2) {
-                    // the pair is (0, 1).  With f = floor(u) the reference's weights are u - f and (f + 1) - u (axis_weights);
-                    // member 0 is tap f + 1 for u in [-1, 0) (weight u + 1) and tap f for u in [0, 1) (weight 1 - u), member 1
-                    // tap f + 1 for u in [0, 1) (weight u) and tap f for u in [1, 2) (weight 2 - u): the same fp32 operations
-                    // on the same operands, picked by one v_med3 each (the smaller of two expressions while both are
-                    // positive, 0 once one is not); NaN and far-away coordinates are pulled to -2 / 3, where both are 0.
-                    // d weight / d u of member 0 is +1 for f = -1 and -1 for f = 0, of member 1 +1 for f = 0 and -1 for
-                    // f = 1, else 0: with c = 2 f + 1 (c - 2) that is -c where |c| = 1.
-                    const float uc = __builtin_amdgcn_fmed3f(uz, -2.0f, 3.0f);
-                    q.wzm[0] = __builtin_amdgcn_fmed3f(0.0f, __fadd_rn(uc, 1.0f), __fsub_rn(1.0f, uc));
-                    q.wzm[1] = __builtin_amdgcn_fmed3f(0.0f, uc, __fsub_rn(2.0f, uc));
+                    // the pair is (0, 1): weights of its members by common.hpp: z_pair_weights.  d weight / d u of
+                    // member 0 is +1 for f = floor(u) = -1 and -1 for f = 0, of member 1 +1 for f = 0 and -1 for f = 1,
+                    // else 0: with c = 2 f + 1 (c - 2) that is -c where |c| = 1.
+                    const float uc = z_pair_weights(uz, q.wzm[0], q.wzm[1]);
                     const float c0 = fmaf(2.0f, floorf(uc), 1.0f), c1 = c0 - 2.0f;
                     q.vz[0] = fabsf(c0) == 1.0f ? -c0 : 0.0f;
                     q.vz[1] = fabsf(c1) == 1.0f ? -c1 : 0.0f;
