@@ -19,6 +19,7 @@ collective the path has; it is a separate mode, never the headline value.
 Rank 0 prints ONE JSON line; it also carries
   roofline      the dominant kernel (the Gram kernel K3n / K3s / K3) timed with HIP events on its stream
   cpu_baseline  the CPU oracle (reference op sequence) timed on this host on a bounded sample, N=1 only
+  ranks         (N > 1) world size, backend and the (rank, device, PCI bus) rows all-gathered over the process group
   extras        (default N=1 run only, outside the timed region, a few sweeps each; --no-extras skips them)
                 depth2: the same sweep at 512x512x2 -- the smallest volume the reference itself can run, 8-tap kernels;
                 with_spatial: the sweep of --with-spatial with its kernel times;
@@ -73,9 +74,48 @@ def parse():
     ap.add_argument("--with-spatial", action="store_true",
                     help="sweep = default + update_footprints(live_spatial=True): K7 registration, K5, ONE all-reduce of "
                          "A1 | C_s over the ranks (RCCL for N > 1), K6 -- the path's only collective")
+    ap.add_argument("--exchange-extra", action="store_true",
+                    help="N > 1 only: after the timed region also run the live footprint update (the path's one all-reduce) "
+                         "twice under a watchdog and report it in extras.sharded_footprint_update; a rank that fails or a "
+                         "collective that does not return makes every rank leave with exit code 3 after rank 0 has printed "
+                         "the line with the error.  Off by default: the default --gpus N line has no post-region hazard "
+                         "(--with-spatial times the collective as the main line)")
+    ap.add_argument("--beta-init", choices=["identity", "displaced"], default="identity",
+                    help="displaced: every frame starts from a smooth warp about a voxel away from the identity (shift, linear "
+                         "and quadratic terms) instead of the identity")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements of the default N=1 run (Z = 2 line, spatial mode, stock DataLoader)")
     return ap.parse_args()
+
+
+class Traffic:
+    """profiles/roofline_traffic.json: HBM bytes and issue statistics per launch from separate rocprofv3 --pmc passes
+    (tools/make_traffic_json.py).  Every entry names the source files its kernel is built from and the file carries their
+    hashes at measurement time; an entry is handed out only when those hashes equal the ones compiled into the library
+    this process loaded (dnmf_build_stamp), else None -- a counter file cannot go stale silently."""
+
+    def __init__(self, lib_stamp):
+        self.entries, self.lib = {}, lib_stamp
+        path = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(path):
+            self.entries = json.load(open(path)).get("entries", {})
+        self.stale = set()
+
+    def get(self, key):
+        e = self.entries.get(key)
+        if e is None:
+            return None
+        src = e.get("sources", {})
+        if not src or any(h is None or h != self.lib.get(f) for f, h in src.items()):
+            self.stale.add(key)
+            return None
+        return e["value"]
+
+    def note(self):
+        if not self.stale:
+            return None
+        return ("entries of profiles/roofline_traffic.json measured on other sources than the loaded library and therefore "
+                "reported as null: " + ", ".join(sorted(self.stale)))
 
 
 def other_kernels(evs, P, K, T_loc, tjson, key, Pp):
@@ -94,6 +134,12 @@ def other_kernels(evs, P, K, T_loc, tjson, key, Pp):
                              "image traffic is meant to stay in the Infinity Cache, so HBM should see ~4PT (traffic)",
                     "traffic": tjson.get(f"{key.split('_K')[0]}_motion")})
     k2 = evs("warp_recon_grad")
+    if k2:
+        ms = 1e3 * sum(k2) / len(k2)
+        b = 4.0 * P * T_loc + 4.0 * Pp * T_loc   # the frame and its reconstruction image (halo layout), each read once
+        out.append(hbm_roof("warp_recon_grad_kernel (K2: warp of the reconstruction image, residual, gradient sums)", ms, b,
+                            "algorithmic bytes 4PT (frames) + 4 halo(P) T (reconstruction images)",
+                            tjson.get(f"{key.split('_K')[0]}_K2")))
     rl = evs("recon_image_lists")
     if rl:
         ms = 1e3 * sum(rl) / len(rl)
@@ -181,7 +227,25 @@ class HostVideo(torch.utils.data.Dataset):
         return sample, idx
 
 
-def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spatial=False, loader="resident"):
+def displaced_beta(T, sz, device, seed=7):
+    """(10,3,T) warps about a voxel off the identity: shifts of +-1 px, linear terms of +-0.2 %, quadratic terms that move
+    the far corner by ~1 px, z row left at the identity; smooth in t (random walk of period ~200 frames).  (Warps several
+    voxels away from where the simulator put the neurons are not a fit any more: a trace whose footprint has lost its
+    neuron grows without bound under the multiplicative update, and fit_sanity rejects the run.)"""
+    g = torch.Generator().manual_seed(seed)
+    S = float(max(sz[0], sz[1]))
+    amp = torch.tensor([1.0] + [0.002] * 3 + [1.0 / S ** 2] * 6)[:, None, None]         # per basis term
+    knots = torch.randn(10, 3, max(2, T // 200 + 2), generator=g)
+    walk = torch.nn.functional.interpolate(knots.reshape(1, 30, -1), size=T, mode="linear", align_corners=True).reshape(10, 3, T)
+    d = amp * walk
+    d[:, 2, :] = 0.0
+    d[[3, 6, 8, 9], :, :] = 0.0     # terms with z
+    ident = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None]
+    return (ident + d).to(device).contiguous()
+
+
+def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spatial=False, loader="resident",
+               beta_init="identity"):
     """Build the workload (synthetic video resident in HBM, model, loaders) and time `steps` sweeps after `warmup`.
     loader = "resident": the fit reads the rows where they lie; "dataloader": a stock torch DataLoader over a host
     copy of the video behind a plain Dataset (demo.py:33-35), every sweep crosses PCIe twice; "dataset": a stock
@@ -203,6 +267,10 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     dn.verbose = False
     dn.gram_kernel = args.gram
     dn.group = group
+    if beta_init == "displaced":
+        with torch.no_grad():
+            dn.fp.beta.copy_(displaced_beta(T_loc, sz, dn.fp.beta.device))
+    beta_start = dn.fp.beta.detach().clone()
     lr = args.lr if args.lr is not None else 1e-5 * (50.0 / sz[0]) ** 2
     opt = torch.optim.Adam([dn.fp.beta], lr=lr)
     if loader == "resident":
@@ -271,6 +339,7 @@ def run_sweeps(args, sz, K, T_loc, steps, warmup, rank, world, group, with_spati
     beta = dn.fp.beta.detach()
     ident = torch.cat((torch.zeros(1, 3), torch.eye(3), torch.zeros(6, 3)), 0)[:, :, None].to(beta.device)
     sanity = {"finite_beta_frames": int(torch.isfinite(beta).all(0).all(0).sum()), "frames": T_loc,
+              "beta_init": beta_init, "max_abs_beta_minus_start": float((beta - beta_start).abs().nan_to_num(float("inf")).max()),
               "finite_trace_entries": int(torch.isfinite(dn.C).sum()), "trace_entries": dn.C.numel(),
               "max_abs_beta_minus_identity": float((beta - ident).abs().nan_to_num(float("inf")).max()),
               "max_trace": float(dn.C.nan_to_num(float("inf")).max()), "lr": lr}
@@ -329,11 +398,33 @@ def sharded_footprint_update(dn, frames, sz, bs, iter_c, group, world, updates=2
             "footprints_identical_on_all_ranks": bool(all(float(v) == float(sums[0]) for v in sums))}
 
 
-def short_line(res, steps):
+def checked_value(res, steps):
+    """frames/s of a run, or (None, the rate) when its fit left the sane range: such a run is not a measurement of the
+    workload (a frame whose beta is not finite costs the kernels nothing)."""
+    v = res["T_total"] * steps / res["elapsed"]
+    return (v, None) if res["sanity"]["ok"] else (None, v)
+
+
+def hbm_roof(kernel, ms, nbytes, count, traffic=None):
+    return {"kernel": kernel, "bound": "hbm", "launch_ms": ms, "bytes_per_launch": nbytes, "achieved": nbytes / ms / 1e6,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS, "count": count,
+            "traffic": traffic}
+
+
+def short_line(res, steps, rooflines=None):
     """frames/s, ms per sweep and the per-kernel HIP-event times of a secondary measurement."""
-    return {"value": res["T_total"] * steps / res["elapsed"], "unit": "frames/s", "steps": steps,
-            "ms_per_step": 1e3 * res["elapsed"] / steps, "sweep_ms_on_stream": res["sweep_ms"], "fit_sanity": res["sanity"],
-            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())}}
+    v, bad = checked_value(res, steps)
+    out = {"value": v, "unit": "frames/s", "steps": steps,
+           "ms_per_step": 1e3 * res["elapsed"] / steps, "sweep_ms_on_stream": res["sweep_ms"], "fit_sanity": res["sanity"],
+           "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(res["per_step_ms"].items())}}
+    if bad is not None:
+        out["value_of_the_invalid_run"] = bad
+    if res.get("lists_counters"):
+        n = max(1, len(res["evs"]("warp_gram_rhs_lists")))
+        out["tile_neuron_evaluations_per_frame"] = res["lists_counters"][0] / n / (res["T_total"])
+    if rooflines:
+        out["rooflines"] = rooflines(res)
+    return out
 
 
 def main():
@@ -365,7 +456,8 @@ def main():
     T_total = T_loc * world
     ntap = 8 if Z > 1 else 4
 
-    res = run_sweeps(args, sz, K, T_loc, args.steps, args.warmup, rank, world, group, with_spatial=args.with_spatial)
+    res = run_sweeps(args, sz, K, T_loc, args.steps, args.warmup, rank, world, group, with_spatial=args.with_spatial,
+                     beta_init=args.beta_init)
     elapsed, evs, dn, frames, positions0 = res["elapsed"], res["evs"], res["dn"], res["frames"], res["positions0"]
 
     # one launch of the dense Gram kernel outside the timed region, for the roofline of the kernel that
@@ -389,10 +481,7 @@ def main():
         # algorithmic flops of one Gram launch when every product is evaluated (symmetric Gram,
         # rhs, 4 or 8 interpolation taps)
         dense_flops = T_loc * (P * K * (K + 1) + 2 * P * K + 2 * ntap * P * K)
-        tjson = {}
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            tjson = json.load(open(tpath))
+        tjson = Traffic(ops.build_stamp())
         key = f"{size}x{size}x{T_loc}_K{K}" if Z == 1 else f"{size}x{size}x{Z}x{T_loc}_K{K}"
         if lists:
             # K3n has no matrix-pipe work; its floor is the traffic it cannot avoid: every frame once, the footprints
@@ -437,7 +526,7 @@ def main():
                     "count": "P*K*(K+1) symmetric Gram + 2PK rhs + 2*taps*PK interpolation, per frame"}
         line = {
             "metric": "frames/sec demixed, 512x512xT K=100",
-            "value": T_total * args.steps / elapsed,
+            "value": checked_value(res, args.steps)[0],
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -465,6 +554,11 @@ def main():
             "fit_sanity": res["sanity"],
             "other_kernels": other_kernels(evs, P, K, T_loc, tjson, key, ops.halo_voxels(sz)),
         }
+        if line["value"] is None:
+            line["value_of_the_invalid_run"] = checked_value(res, args.steps)[1]
+            line["invalid"] = "fit_sanity.ok is false: the sweeps did not work on a sane fit, the rate is not a measurement"
+        if tjson.note():
+            line["traffic_note"] = tjson.note()
         if world == 1 and not args.no_cpu_baseline and Z == 1:
             line["cpu_baseline"] = cpu_baseline(size, K, bs, args.iter_c, positions0.numpy(), frames[:bs].cpu().numpy(), res["lr"])
 
@@ -475,12 +569,48 @@ def main():
         extras = {}
         # the smallest volume the reference itself can run has two slices (Demix/dNMF.py:55 divides by Z-1)
         r2 = run_sweeps(args, [size, size, 2], K, T_loc, 5, 2, 0, 1, None)
-        extras["depth2"] = dict(short_line(r2, 5), workload=f"{size}x{size}x2x{T_loc}, K={K}: the 8-tap kernel variants")
+        tj = Traffic(ops.build_stamp())
+        key2 = f"{size}x{size}x2x{T_loc}_K{K}"
+
+        def roofs_depth2(r):
+            P2 = 2 * P
+            out = []
+            k3 = r["evs"]("warp_gram_rhs_lists")
+            if k3:
+                ab = 4.0 * P2 * T_loc + 4.0 * P2 * K + 4.0 * T_loc * (K * K + K)
+                out.append(dict(hbm_roof("K3n at Z = 2: lists_tilemask_kernel + warp_gram_lists_kernel<2,...> (both passes)",
+                                         1e3 * sum(k3) / len(k3), ab, "frames 4PT + footprints 4PK + G, r 4T(K^2+K)",
+                                         tj.get(key2 + "_lists")), valu_issue=tj.get(key2 + "_lists_valu")))
+            out += other_kernels(r["evs"], P2, K, T_loc, tj, key2, ops.halo_voxels([size, size, 2]))
+            return out
+
+        extras["depth2"] = dict(short_line(r2, 5, roofs_depth2), workload=f"{size}x{size}x2x{T_loc}, K={K}: the 8-tap kernel variants")
         del r2
         torch.cuda.empty_cache()
         # the footprint update the reference leaves commented out, wired in (K7 registration + K5 + K6)
         r3 = run_sweeps(args, sz, K, T_loc, 3, 1, 0, 1, None, with_spatial=True)
-        extras["with_spatial"] = dict(short_line(r3, 3), workload="the default sweep + update_footprints(live_spatial=True)")
+
+        def roofs_spatial(r):
+            out = []
+            k7 = r["evs"]("image_iwarp")
+            if k7:
+                out.append(hbm_roof("image_iwarp kernels (K7: nearest warped voxel of every lattice point)",
+                                    1e3 * sum(k7) / len(k7), 8.0 * P * T_loc, "frames read 4PT + registered frames written 4PT"))
+            for name in ("spatial_accum", "spatial_accum_lists"):
+                k5 = r["evs"](name)
+                if k5:
+                    out.append(hbm_roof(f"{name} (K5: A1 = Y_i C^T over the frames)", 1e3 * sum(k5) / len(k5),
+                                        4.0 * P * T_loc + 4.0 * K * T_loc + 4.0 * P * K,
+                                        "registered frames 4PT + traces 4KT read, A1 4PK written"))
+            return out
+
+        extras["with_spatial"] = dict(short_line(r3, 3, roofs_spatial), workload="the default sweep + update_footprints(live_spatial=True)")
+        del r3
+        torch.cuda.empty_cache()
+        # the same sweep from warps a few voxels off the identity (longer tile lists, K7 windows beyond one cell)
+        r3 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, beta_init="displaced")
+        extras["displaced_beta"] = dict(short_line(r3, 5), workload="the default sweep started from smooth warps a few voxels "
+                                        "off the identity (bench.py: displaced_beta) instead of the identity")
         del r3
         torch.cuda.empty_cache()
         # what demo.py really drives: a stock DataLoader over a host video (PCIe-inclusive, host-bound)
@@ -501,33 +631,66 @@ def main():
                                                    "copy of the video, as demo.py:33-35; every sweep serves the video twice "
                                                    "from the host (update_motion, update_footprints)")
         line["extras"] = extras
-    # N > 1: the sweep above shards without any collective; the path's one real exchange (the footprint update's
-    # all-reduce) is exercised here, outside the timed region, under a watchdog -- if any rank fails or the collective
-    # does not come back, rank 0 still prints the line (without this entry) and every rank leaves
-    if world > 1 and not args.no_extras and not args.with_spatial and Z == 1 and K <= 128:
+    # N > 1: who took part.  One all-gather of (rank, device ordinal, PCI bus id) over the process group the sweeps ran
+    # under: N distinct devices = N RCCL ranks, without NCCL_DEBUG.
+    if world > 1:
+        import torch.distributed as dist
+        props = torch.cuda.get_device_properties(dev_index)
+        mine = torch.tensor([rank, dev_index, int(getattr(props, "pci_bus_id", -1)), int(getattr(props, "pci_device_id", -1))],
+                            dtype=torch.int64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine, group=group)
+        if rank == 0:
+            rows = [[int(v) for v in t.tolist()] for t in allr]
+            line["ranks"] = {"world_size": dist.get_world_size(group), "backend": dist.get_backend(group),
+                             "rank_device_pcibus_pcidev": rows,
+                             "distinct_devices": len({(r[1], r[2], r[3]) for r in rows})}
+    # N > 1, --exchange-extra: the sweep above shards without any collective; the path's one real exchange (the footprint
+    # update's all-reduce) is exercised here, outside the timed region, under a watchdog.  A rank that fails writes its
+    # error where the others' watchdogs see it; then rank 0 prints the line WITH the error and every rank leaves with exit
+    # code 3 -- a process that has touched the GPU and gives up must not look like a clean run.
+    if world > 1 and args.exchange_extra and not args.with_spatial and Z == 1 and K <= 128:
+        import glob
+        import tempfile
+        tag = os.path.join(tempfile.gettempdir(), f"dnmf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
         finished = threading.Event()
 
-        def bail():
+        def bail(reason):
             if finished.is_set():
                 return
             if rank == 0:
-                line["extras"] = {"sharded_footprint_update": {"error": "no answer within 240 s"}}
+                line.setdefault("extras", {})["sharded_footprint_update"] = {"error": reason}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
 
-        timer = threading.Timer(240.0, bail)
-        timer.daemon = True
-        timer.start()
+        def watch():
+            t_end = time.time() + 240.0
+            while not finished.is_set():
+                errs = sorted(glob.glob(tag + "_err_*"))
+                if errs:
+                    time.sleep(0.2)   # let the writer finish
+                    bail("; ".join(open(f).read().strip()[:300] for f in errs))
+                if time.time() > t_end:
+                    bail("no answer within 240 s (a collective did not return)")
+                time.sleep(0.5)
+
+        if rank == 0:                      # error notes of an earlier run under the same launcher
+            for f in glob.glob(tag + "_err_*"):
+                os.remove(f)
+        torch.distributed.barrier()
+        watcher = threading.Thread(target=watch, daemon=True)
+        watcher.start()
+        ex = None
         try:
             ex = sharded_footprint_update(dn, frames, sz, bs, args.iter_c, group, world)
-        except Exception as err:   # the other ranks are stuck in the collective: leave through the watchdog
+        except Exception as err:   # the other ranks are stuck in the collective: tell their watchdogs, leave through ours
             print(f"[bench] rank {rank}: sharded_footprint_update failed: {err!r}", file=sys.stderr, flush=True)
-            time.sleep(300.0)
-            ex = None
+            with open(f"{tag}_err_{rank}", "w") as f:
+                f.write(f"rank {rank}: {err!r}")
+            time.sleep(300.0)          # the watcher thread ends the process
         finished.set()
-        timer.cancel()
         if rank == 0 and ex is not None:
-            line["extras"] = {"sharded_footprint_update": ex}
+            line.setdefault("extras", {})["sharded_footprint_update"] = ex
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DNMF_LIB selects another build of the library (kernel-variant timing, ablations); the product default is in-tree
 LIB_PATH = os.environ.get("DNMF_LIB") or os.path.join(_HERE, "libdnmf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 
@@ -18,6 +18,7 @@ _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 SIGNATURES = {
     "dnmf_version": (_i, []),
     "dnmf_last_error": (C.c_char_p, []),
+    "dnmf_build_stamp": (C.c_char_p, []),
     "dnmf_padded_k": (_i, [_i]),
     "dnmf_pack_footprints": (_i, [_vp, _l, _i, _vp, _i, _vp]),
     "dnmf_warp_gather": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),

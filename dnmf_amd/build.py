@@ -46,6 +46,14 @@ PER_FILE_FLAGS = {
 }
 
 
+def source_hashes() -> dict:
+    """{file name: first 12 hex digits of its sha256} for every file under csrc/ and the public header."""
+    import hashlib
+    files = {f: os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))}
+    files["dnmf_hip.h"] = os.path.join(HERE, "..", "include", "dnmf_hip.h")
+    return {name: hashlib.sha256(open(path, "rb").read()).hexdigest()[:12] for name, path in files.items()}
+
+
 def _compile_one(job):
     cmd, src = job
     subprocess.run(cmd, check=True)
@@ -78,8 +86,11 @@ def build_library(force: bool = False, verbose: bool = True, out: str | None = N
     headers.append(os.path.join(HERE, "..", "include", "dnmf_hip.h"))
     hdr_time = max(os.path.getmtime(h) for h in headers)
     jobs, objs = [], []
+    stamp = "-DDNMF_BUILD_STAMP=\"" + ";".join(f"{k}:{v}" for k, v in sorted(source_hashes().items())) + "\""
     for s in SOURCES:
         extra = [*PER_FILE_FLAGS.get(s, []), *(defines if (only is None or s in only) else [])]
+        if s == "api_common.hip":
+            extra.append(stamp)
         src, obj = os.path.join(CSRC, s), os.path.join(objdir_for(extra), s + ".o")
         objs.append(obj)
         dep_time = max([os.path.getmtime(src), hdr_time, *[os.path.getmtime(os.path.join(CSRC, d)) for d in EXTRA_DEPS.get(s, [])]])

@@ -39,6 +39,11 @@ int dnmf_version(void) { return DNMF_ABI_VERSION; }
 
 const char *dnmf_last_error(void) { return dnmf::last_error_buffer(); }
 
+#ifndef DNMF_BUILD_STAMP
+#define DNMF_BUILD_STAMP ""
+#endif
+const char *dnmf_build_stamp(void) { return DNMF_BUILD_STAMP; }
+
 int dnmf_padded_k(int K) { return K < 1 ? 0 : 16 * ((K + 1 + 15) / 16); }
 
 int dnmf_pack_footprints(const float *A, long P, int K, float *Apk, int Kp, dnmf_stream_t stream) {

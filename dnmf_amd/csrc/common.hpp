@@ -299,11 +299,15 @@ __device__ __forceinline__ void make_taps(const Sample &sm, const Volume &vol, f
 // ---- where the taps of a box of voxels can fall ------------------------------------------------------------
 // Conservative range of a_d = 2 q_d over a box of voxel coordinates lo <= (x,y,z) <= hi, all >= 0: every monomial is
 // monotone there, so a term's range follows from the sign of its coefficient (interval arithmetic on the ten terms).
+// `mag` receives the sum of the magnitudes of the ten terms at the far corner of the box: the partial sums of either
+// evaluation (the interval arithmetic here, the FMA chain of poly_a) stay below it, so each of their ~10 roundings is
+// at most mag 2^-24.
 __device__ __forceinline__ void poly_range(const float *b, int d, const float (&lo)[3], const float (&hi)[3], bool hasz,
-                                           float &amin, float &amax) {
+                                           float &amin, float &amax, float &mag) {
     const float mlo[9] = {lo[0], lo[1], lo[2], lo[0] * lo[0], lo[1] * lo[1], lo[2] * lo[2], lo[0] * lo[1], lo[0] * lo[2], lo[1] * lo[2]};
     const float mhi[9] = {hi[0], hi[1], hi[2], hi[0] * hi[0], hi[1] * hi[1], hi[2] * hi[2], hi[0] * hi[1], hi[0] * hi[2], hi[1] * hi[2]};
     amin = amax = b[d];
+    mag = fabsf(b[d]);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const bool zterm = i == 2 || i == 5 || i == 7 || i == 8;
@@ -311,21 +315,27 @@ __device__ __forceinline__ void poly_range(const float *b, int d, const float (&
         const float c = b[3 * (i + 1) + d];
         const float p = c * mlo[i], q = c * mhi[i];
         amin += fminf(p, q), amax += fmaxf(p, q);
+        mag += fabsf(q);
     }
-    amin *= 2.0f, amax *= 2.0f;
+    amin *= 2.0f, amax *= 2.0f, mag *= 2.0f;
 }
 
 // Integer range [a, c] that contains the base corner AND the second corner (base + 1) along axis d of every voxel of the
 // box, clamped to [-4, S + 5]: the source coordinate is a non-decreasing function of a_d, so its range follows from
-// poly_range; the margin is far above the fp32 rounding of either evaluation (a few roundings at magnitudes up to ~2S,
-// i.e. errors of order S * 1e-6 voxels).  False when the coordinates are NaN (such voxels gather zeros from the halo).
+// poly_range; the margin covers the fp32 rounding of either evaluation: a fixed part for the normalise / un-normalise
+// round trip (a few roundings at magnitudes up to ~2S: errors of order S * 1e-6 voxels) plus 2^-20 of the summed term
+// magnitudes -- with large quadratic coefficients whose terms cancel (|c| S^2 >> S while the voxel stays in the volume)
+// the partial sums, and with them the rounding of the ten-term chain, are far larger than the coordinate itself; a fixed
+// margin would then drop a neuron from a tile's list without a trace (tests/test_gpu_parity.py:
+// test_neuron_list_gram_with_cancelling_quadratic_terms).  False when the coordinates are NaN (such voxels gather zeros
+// from the halo).
 __device__ __forceinline__ bool tap_range(const float *b, const Volume &vol, int d, const float (&lo)[3], const float (&hi)[3],
                                           bool hasz, int &a, int &c) {
     const int S = d == 0 ? vol.X : (d == 1 ? vol.Y : vol.Z);
     const float h = d == 0 ? vol.hx1 : (d == 1 ? vol.hy1 : vol.hz1);
-    float amin, amax;
-    poly_range(b, d, lo, hi, hasz, amin, amax);
-    const float margin = 0.0625f + 4e-6f * (float)S;
+    float amin, amax, mag;
+    poly_range(b, d, lo, hi, hasz, amin, amax, mag);
+    const float margin = 0.0625f + 4e-6f * (float)S + 9.54e-7f * mag;
     const float ulo = unnormalise(normalise_axis<-1>(amin, vol, d), h) - margin;
     const float uhi = unnormalise(normalise_axis<-1>(amax, vol, d), h) + margin;
     if (!(ulo <= uhi)) return false;

@@ -49,6 +49,12 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def build_stamp() -> dict:
+    """{source file: hash} the loaded library was compiled from (``dnmf_build_stamp``; dnmf_amd/build.py makes it)."""
+    text = _lib.load().dnmf_build_stamp().decode()
+    return dict(item.split(":", 1) for item in text.split(";") if ":" in item)
+
+
 def padded_k(K: int) -> int:
     return _lib.load().dnmf_padded_k(int(K))
 
@@ -478,7 +484,9 @@ def image_iwarp(frames, frame_ids, sz, beta, times, out=None, exhaustive=False, 
     if out.shape[0] < B or out.stride(0) < P or out.stride(1) != 1:
         raise ValueError("image_iwarp: out must be (>=B, ld) with ld >= P")
     lib = _lib.load()
-    step = 16384   # frames per launch (gridDim.y); one flag byte per lattice point of the launch
+    # frames per launch (gridDim.y); one flag byte per lattice point of the launch: at most 256 MiB of flags (a 512x512x20
+    # volume would otherwise ask for 86 GB per 16384-frame launch)
+    step = max(1, min(16384, (256 << 20) // P))
     ws = torch.empty((lib.dnmf_image_iwarp_workspace(X, Y, Z, min(B, step)),), dtype=torch.uint8, device=dev)
     for s in range(0, B, step):
         n = min(step, B - s)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DNMF_ABI_VERSION 3
+#define DNMF_ABI_VERSION 4
 
 #define DNMF_OK 0
 #define DNMF_E_NULL (-1)      /* required pointer is NULL */
@@ -56,6 +56,10 @@ long dnmf_halo_voxels(int X, int Y, int Z);
 int dnmf_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char *dnmf_last_error(void);
+/* "file:hash;file:hash;..." of the sources this library was compiled from (dnmf_amd/build.py computes the hashes and
+ * passes them at compile time; "" for a build made without it).  bench.py reports counter data from profiles/ only when
+ * the hashes recorded with them equal these. */
+const char *dnmf_build_stamp(void);
 
 /* ---- packed footprints ---------------------------------------------------------------------
  * The Gram kernel reads footprints from a zero-padded copy with row length Kp = 16*ceil((K+1)/16)
