@@ -62,6 +62,10 @@ SIGNATURES = {
     "dnmf_motion_grad_lists_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dnmf_motion_grad_lists": (_i, [_vp, _vp, _i, _vp, _l, _vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i,
                                     _vp, _sz, _vp]),
+    "dnmf_register_patches_grid": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dnmf_register_patches_workspace": (_sz, [_i, _i, _i, _vp, _vp, _i]),
+    "dnmf_register_patches": (_i, [_vp, _l, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "dnmf_apply_shifts_points": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "dnmf_comm_unique_id": (_i, [_vp]),
     "dnmf_comm_init": (_i, [_vp, _vp, _i, _i]),
     "dnmf_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdnmf_hip.so")
 SOURCES = ["api_common.hip", "warp_gather.hip", "recon_image.hip", "warp_recon_grad.hip", "warp_gram_rhs.hip", "warp_gram_sparse.hip", "warp_gram_lists.hip", "warp_gram_lists_z.hip", "recon_lists.hip",
-           "mu_temporal.hip", "render_frames.hip", "adam_epoch.hip", "spatial_update.hip", "image_iwarp.hip", "collective.hip"]
+           "mu_temporal.hip", "render_frames.hip", "adam_epoch.hip", "spatial_update.hip", "image_iwarp.hip", "register_patches.hip", "collective.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 

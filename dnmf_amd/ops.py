@@ -500,6 +500,66 @@ def image_iwarp(frames, frame_ids, sz, beta, times, out=None, exhaustive=False, 
     return out
 
 
+def patch_grid(sz, strides, overlaps):
+    """The patch grid of the reference's ``sliding_window_3d`` (MotionCorrect.py:1190-1221): ``(dims (3,), starts (NP,3))`` as
+    numpy int arrays, patches in the reference's order (x outermost)."""
+    import ctypes
+
+    import numpy as np
+    X, Y, Z = (int(s) for s in sz)
+    st = (ctypes.c_int * 3)(*[int(v) for v in strides])
+    ov = (ctypes.c_int * 3)(*[int(v) for v in overlaps])
+    dims = (ctypes.c_int * 3)()
+    lib = _lib.load()
+    NP = lib.dnmf_register_patches_grid(X, Y, Z, st, ov, dims, None)
+    if NP <= 0:
+        raise ValueError(f"patch_grid: windows of strides {tuple(strides)} + overlaps {tuple(overlaps)} do not fit the volume {X}x{Y}x{Z}")
+    starts = (ctypes.c_int * (3 * NP))()
+    lib.dnmf_register_patches_grid(X, Y, Z, st, ov, dims, starts)
+    return np.array(list(dims)), np.array(list(starts)).reshape(NP, 3)
+
+
+def register_patches(frames, tmpl, sz, strides, overlaps, max_shifts, max_deviation_rigid=3, upsample_factor=10,
+                     add_to_movie=0.0, frame_ids=None):
+    """K8.  frames (>=B, P) fp32 CUDA rows, tmpl (P) -> rigid shifts (B,3) and per-patch shifts (B,NP,3) (signs -x, -y, +z:
+    the reference's ``x/y/z_shifts_els``)."""
+    import ctypes
+    X, Y, Z = (int(s) for s in sz)
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("register_patches: frames must be float32 CUDA with unit inner stride")
+    dev = frames.device
+    tm = _f32(tmpl.reshape(-1), "tmpl")
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = fid.numel() if fid is not None else frames.shape[0]
+    st = (ctypes.c_int * 3)(*[int(v) for v in strides])
+    ov = (ctypes.c_int * 3)(*[int(v) for v in overlaps])
+    ms = (ctypes.c_int * 3)(*[int(v) for v in max_shifts])
+    lib = _lib.load()
+    NP = lib.dnmf_register_patches_grid(X, Y, Z, st, ov, None, None)
+    if NP <= 0:
+        raise ValueError(f"register_patches: windows of strides {tuple(strides)} + overlaps {tuple(overlaps)} do not fit the volume")
+    need = lib.dnmf_register_patches_workspace(X, Y, Z, st, ov, B)
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    rigid = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    patch = torch.empty((B, NP, 3), dtype=torch.float32, device=dev)
+    with _timed("register_patches"):
+        rc = lib.dnmf_register_patches(frames.data_ptr(), frames.stride(0), _ptr(fid), B, tm.data_ptr(), X, Y, Z, st, ov, ms,
+                                       int(max_deviation_rigid), int(upsample_factor), float(add_to_movie), rigid.data_ptr(),
+                                       patch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "dnmf_register_patches")
+    return rigid, patch
+
+
+def apply_shifts_points(points, patch_shifts, centers):
+    """points (K,3), patch_shifts (T,NP,3), centers (NP,3) -> (K,3,T) fp32 (MotionCorrect.apply_shifts_points)."""
+    pts, sh, ce = _f32(points, "points"), _f32(patch_shifts, "patch_shifts"), _f32(centers, "centers")
+    K, (T, NP, _) = pts.shape[0], sh.shape
+    out = torch.empty((K, 3, T), dtype=torch.float32, device=pts.device)
+    _lib.check(_lib.load().dnmf_apply_shifts_points(pts.data_ptr(), K, sh.data_ptr(), T, NP, ce.data_ptr(), out.data_ptr(), _stream()),
+               "dnmf_apply_shifts_points")
+    return out
+
+
 def pack_footprints_sparse(A, order):
     """A (..., K) and a neuron order -> (Aps (P,Ks), row_mask (P) uint8) for the zero-skipping Gram kernel."""
     K = A.shape[-1]

@@ -318,6 +318,33 @@ int dnmf_render_frames(const float *positions, const double *traces, int K, int 
                        int Y, int Z, double shape_std, double amp_max, float *out, long ldo,
                        dnmf_stream_t stream);
 
+/* ---- K8: position initialiser ----------------------------------------------------------------------
+ * Reference: Demix/MotionCorrect.py -- MotionCorrect.motion_correct_pwrigid :260-328 -> tile_and_correct_3d :1518-1608
+ * (per frame: rigid shift, then one shift per patch inside rigid +- max_deviation_rigid; register_translation_3d :648-797 with
+ * the matrix-multiply upsampled DFT :498-614) and MotionCorrect.apply_shifts_points :351-371.  The module is an orphan of
+ * the reference tree, cannot be imported in the build container and has no fixtures: parity is pinned only against the
+ * restatement oracle/motion_oracle.py ("parity unpinned").
+ *
+ * dnmf_register_patches_grid: the patch grid of sliding_window_3d :1190-1221 (windows of strides + overlaps every `strides`,
+ * the last one flush with the end).  Returns the number of patches NP (0: the windows do not fit), dims[3] = patches per
+ * axis, starts (NP,3) = first voxel of each patch in the reference's order (x outermost); dims / starts may be NULL (host
+ * pointers).
+ * dnmf_register_patches: frames (>= B rows of ldf floats, voxel p = (x Y + y) Z + z; row frame_ids[b] or b), tmpl (X Y Z)
+ * -> rigid_shifts (B,3) as register_translation_3d returns them, patch_shifts (B,NP,3) with the signs of
+ * tile_and_correct_3d's total_shifts (-x, -y, +z), i.e. what the class stores in x/y/z_shifts_els.  strides, overlaps,
+ * max_shifts: 3 host ints each.  All device buffers fp32. */
+int dnmf_register_patches_grid(int X, int Y, int Z, const int *strides, const int *overlaps, int *dims, int *starts);
+size_t dnmf_register_patches_workspace(int X, int Y, int Z, const int *strides, const int *overlaps, int B);
+int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, int B, const float *tmpl, int X, int Y, int Z,
+                          const int *strides, const int *overlaps, const int *max_shifts, int max_deviation_rigid,
+                          int upsample_factor, float add_to_movie, float *rigid_shifts, float *patch_shifts, void *workspace,
+                          size_t workspace_bytes, dnmf_stream_t stream);
+/* apply_shifts_points :351-371: points (K,3), patch_shifts (T,NP,3) as above, centers (NP,3) = patch start + strides / 2 ->
+ * out (K,3,T): out[k,0/1,t] = p - (s[t] - s[0]), out[k,2,t] = p + (s[t] - s[0]) with s the shifts of the patch whose
+ * centre is nearest to point k. */
+int dnmf_apply_shifts_points(const float *points, int K, const float *patch_shifts, int T, int NP, const float *centers, float *out,
+                             dnmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

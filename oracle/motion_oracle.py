@@ -1,0 +1,158 @@
+"""CPU restatement of the position initialiser of the reference: piecewise-rigid registration shifts of a 3-D video and
+their application to neuron centres.  TEST INFRASTRUCTURE ONLY -- nothing under dnmf_amd/ imports this.
+
+Reference: /root/reference/Demix/MotionCorrect.py (a vendored copy of CaImAn / NoRMCorre, called by nothing in the
+reference tree).  **Parity unpinned**: that module cannot be imported in the build container (it needs cv2, skimage and
+`past`, none of which is installed, and uses `np.int`, removed from numpy 2), and the reference ships no test, fixture or
+output for it.  What follows restates, from the source text, exactly the part `apply_shifts_points` needs -- the shifts
+`x_shifts_els / y_shifts_els / z_shifts_els` of the 3-D piecewise-rigid pass with the class defaults
+(`shifts_opencv=True`) -- with `numpy.fft` where the reference calls `np.fft` (the 3-D functions never use cv2.dft):
+
+  sliding_window_3d        MotionCorrect.py:1190-1221   the patch grid
+  _upsampled_dft           :498-614                     matrix-multiply DFT of a small upsampled region
+  register_translation_3d  :648-797                     integer peak of the circular cross-correlation inside a window,
+                                                        refined to 1/upsample_factor by the upsampled DFT
+  tile_shifts_3d           :1518-1608 (tile_and_correct_3d up to `total_shifts`), called per frame by
+                           tile_and_correct_wrapper :2004-2060 with upsample_factor_fft=10
+  apply_shifts_points      :351-371
+
+Not restated (not needed for the shifts): the corrected frames (`warp_sk`, `apply_shifts_dft`), the template refinement
+by a rigid pass (`motion_correct_batch_rigid` :1770-1877: the caller passes a template), the 2-D (cv2) functions, the
+`shifts_opencv=False` branch (cubic resize of the shift field, skimage).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def patch_starts(size, overlap, stride):
+    """Start offsets of the patches along one axis (sliding_window_3d :1207-1213): windows of overlap + stride voxels every
+    `stride`, the last one flush with the end."""
+    w = overlap + stride
+    return list(range(0, size - w, stride)) + [size - w]
+
+
+def sliding_window_3d(shape, overlaps, strides):
+    """[(dim_1, dim_2, dim_3, x, y, z)] in the reference's iteration order (x outermost), :1214-1221."""
+    r = [patch_starts(shape[d], overlaps[d], strides[d]) for d in range(3)]
+    return [(i, j, k, x, y, z) for i, x in enumerate(r[0]) for j, y in enumerate(r[1]) for k, z in enumerate(r[2])]
+
+
+def _signed_freq(n):
+    """ifftshift(arange(n)) - floor(n / 2) (:585-598): the signed frequency of DFT index j."""
+    return np.fft.ifftshift(np.arange(n)) - np.floor(n / 2)
+
+
+def upsampled_dft(data, region, upsample_factor, axis_offsets):
+    """_upsampled_dft :498-614 for 3-D data: sum_j data[j] exp(-2 pi i f_j (u - offset) / (n upsample_factor)) on a
+    `region`^3 grid of u."""
+    out = data
+    kern = []
+    for d in range(3):
+        n = data.shape[d]
+        u = np.arange(region) - axis_offsets[d]
+        kern.append(np.exp((-2j * np.pi / (n * upsample_factor)) * np.outer(u, _signed_freq(n))))   # (region, n)
+    out = np.tensordot(kern[0], out, axes=[1, 0])           # (r, n1, n2)
+    out = np.tensordot(out, kern[1].T, axes=[1, 0])          # (r, n2, r)   :606
+    out = np.tensordot(out, kern[2], axes=[1, 1])            # (r, r, r)    :611
+    return out
+
+
+def _zero_outside(cc, shifts_lb, shifts_ub, max_shifts):
+    """The window of admissible shifts, by numpy slicing exactly as :727-747 writes it."""
+    if shifts_lb is not None or shifts_ub is not None:
+        for d in range(3):
+            sl = [slice(None)] * 3
+            if shifts_lb[d] < 0 and shifts_ub[d] >= 0:
+                sl[d] = slice(shifts_ub[d], shifts_lb[d])
+                cc[tuple(sl)] = 0
+            else:
+                sl[d] = slice(None, shifts_lb[d])
+                cc[tuple(sl)] = 0
+                sl[d] = slice(shifts_ub[d], None)
+                cc[tuple(sl)] = 0
+    else:
+        for d in range(3):
+            sl = [slice(None)] * 3
+            sl[d] = slice(max_shifts[d], -max_shifts[d])
+            cc[tuple(sl)] = 0
+    return cc
+
+
+def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_lb=None, shifts_ub=None, max_shifts=(10, 10, 10)):
+    """:648-797, space='real'.  Returns the shift vector (3,) float64."""
+    src_freq = np.fft.fftn(np.asarray(src_image, dtype=np.complex128))
+    target_freq = np.fft.fftn(np.asarray(target_image, dtype=np.complex128))
+    shape = src_freq.shape
+    image_product = src_freq * target_freq.conj()
+    cross_correlation = np.fft.ifftn(image_product)
+    new_cc = _zero_outside(np.abs(cross_correlation), shifts_lb, shifts_ub, max_shifts)
+    maxima = np.unravel_index(np.argmax(new_cc), new_cc.shape)
+    midpoints = np.array([np.fix(s // 2) for s in shape])
+    shifts = np.array(maxima, dtype=np.float32)
+    shifts[shifts > midpoints] -= np.array(shape)[shifts > midpoints]
+    if upsample_factor > 1:
+        shifts = np.round(shifts * upsample_factor) / upsample_factor
+        region = int(np.ceil(upsample_factor * 1.5))
+        dftshift = np.fix(region / 2.0)
+        offset = dftshift - shifts * upsample_factor
+        cc = upsampled_dft(image_product.conj(), region, float(upsample_factor), offset).conj()
+        maxima = np.array(np.unravel_index(np.argmax(np.abs(cc)), cc.shape), dtype=np.float64) - dftshift
+        shifts = shifts + maxima / upsample_factor
+    for d in range(3):
+        if shape[d] == 1:
+            shifts[d] = 0
+    return np.asarray(shifts, dtype=np.float64)
+
+
+def tile_shifts_3d(img, template, strides, overlaps, max_shifts, upsample_factor_fft=10, max_deviation_rigid=3,
+                   add_to_movie=0.0):
+    """tile_and_correct_3d :1518-1608 up to its `total_shifts` (shifts_opencv=True branch): the rigid shift, then one
+    shift per patch inside [rigid - max_deviation, rigid + max_deviation].  Returns (rigid (3,), total_shifts (NP,3)) with
+    the reference's sign convention (-x, -y, +z) :1596-1597."""
+    img = np.asarray(img, dtype=np.float64) + add_to_movie
+    template = np.asarray(template, dtype=np.float64) + add_to_movie
+    rigid = register_translation_3d(img, template, upsample_factor=upsample_factor_fft, max_shifts=max_shifts)
+    lb = np.ceil(np.subtract(rigid, max_deviation_rigid)).astype(int)
+    ub = np.floor(np.add(rigid, max_deviation_rigid)).astype(int)
+    w = np.add(overlaps, strides)
+    out = []
+    for (_, _, _, x, y, z) in sliding_window_3d(img.shape, overlaps, strides):
+        a = img[x:x + w[0], y:y + w[1], z:z + w[2]]
+        b = template[x:x + w[0], y:y + w[1], z:z + w[2]]
+        s = register_translation_3d(a, b, upsample_factor_fft, shifts_lb=lb, shifts_ub=ub, max_shifts=max_shifts)
+        out.append((-s[0], -s[1], s[2]))
+    return rigid, np.array(out, dtype=np.float64)
+
+
+def patch_centers(shape, overlaps, strides):
+    """Patch start + strides / 2 (:366), (NP,3)."""
+    return np.array([np.array(it[3:6]) + np.array(strides) / 2 for it in sliding_window_3d(shape, overlaps, strides)], dtype=np.float64)
+
+
+def apply_shifts_points(shifts_x, shifts_y, shifts_z, shape, overlaps, strides, points):
+    """MotionCorrect.apply_shifts_points :351-371.  shifts_* (T, NP); points (K,3).  Returns P_T (K,3,T) float64."""
+    from scipy.spatial import distance
+    points = np.asarray(points, dtype=np.float64)
+    T = shifts_x.shape[0]
+    idx = distance.cdist(patch_centers(shape, overlaps, strides), points).argmin(0)
+    P_T = np.zeros((points.shape[0], 3, T))
+    for t in range(T):
+        P_T[:, :, t] = points
+        P_T[:, 0, t] = P_T[:, 0, t] - shifts_x[t, idx] + shifts_x[0, idx]
+        P_T[:, 1, t] = P_T[:, 1, t] - shifts_y[t, idx] + shifts_y[0, idx]
+        P_T[:, 2, t] = P_T[:, 2, t] + shifts_z[t, idx] - shifts_z[0, idx]
+    return P_T
+
+
+def pw_rigid_shifts(video, template, strides, overlaps, max_shifts, upsample_factor_fft=10, max_deviation_rigid=3,
+                    add_to_movie=0.0):
+    """x/y/z_shifts_els of MotionCorrect.motion_correct_pwrigid (:260-328 -> motion_correct_batch_pwrigid :1880-2000 ->
+    tile_and_correct_wrapper :2004-2060) for a video (T,X,Y,Z) against a given template: three (T, NP) arrays, plus the
+    rigid shifts (T,3)."""
+    sx, sy, sz, rig = [], [], [], []
+    for img in video:
+        r, ts = tile_shifts_3d(img, template, strides, overlaps, max_shifts, upsample_factor_fft, max_deviation_rigid, add_to_movie)
+        rig.append(r)
+        sx.append(ts[:, 0]), sy.append(ts[:, 1]), sz.append(ts[:, 2])
+    return np.array(sx), np.array(sy), np.array(sz), np.array(rig)

@@ -1,0 +1,64 @@
+"""oracle/motion_oracle.py (CPU restatement of the reference's Demix/MotionCorrect.py functions behind apply_shifts_points;
+parity unpinned: the module cannot be imported here and has no fixtures) against properties the algorithm must have:
+circular shifts by whole voxels and by tenths are recovered exactly, the patch grid is sliding_window_3d's, points follow
+their nearest patch relative to frame 0."""
+import numpy as np
+
+
+def smooth_volume(shape, seed=0):
+    from scipy.ndimage import gaussian_filter
+    return gaussian_filter(np.random.RandomState(seed).rand(*shape), (2.0, 2.0, 0.8), mode="wrap")
+
+
+def fourier_shift(v, d):
+    """v moved by the (fractional) displacement d with periodic (Fourier) interpolation: out(x) = v(x - d)."""
+    F = np.fft.fftn(v)
+    for ax, n in enumerate(v.shape):
+        f = np.fft.fftfreq(n)
+        ph = np.exp(-2j * np.pi * f * d[ax])
+        if n % 2 == 0:
+            ph[n // 2] = np.cos(np.pi * d[ax])      # keep the result real
+        F = F * ph.reshape([-1 if a == ax else 1 for a in range(3)])
+    return np.fft.ifftn(F).real
+
+
+def test_patch_grid_is_sliding_window_3d():
+    from oracle import motion_oracle as MO
+    assert MO.patch_starts(50, 8, 16) == [0, 16, 26]            # range(0, 50 - 24, 16) + [50 - 24]
+    assert MO.patch_starts(24, 8, 16) == [0]
+    g = MO.sliding_window_3d((50, 40, 2), (8, 8, 1), (16, 12, 1))
+    assert g[0] == (0, 0, 0, 0, 0, 0) and g[1][:3] == (0, 1, 0) and g[-1][3:] == (26, 20, 0)
+    np.testing.assert_array_equal(MO.patch_centers((50, 40, 2), (8, 8, 1), (16, 12, 1))[0], [8, 6, 0.5])
+
+
+def test_register_translation_recovers_circular_shifts():
+    from oracle import motion_oracle as MO
+    tm = smooth_volume((40, 36, 4))
+    img = np.roll(tm, (3, -2, 1), axis=(0, 1, 2))
+    np.testing.assert_allclose(MO.register_translation_3d(img, tm, 1, max_shifts=(6, 6, 2)), [3, -2, 1])
+    np.testing.assert_allclose(MO.register_translation_3d(img, tm, 10, max_shifts=(6, 6, 2)), [3, -2, 1], atol=1e-6)
+    img = fourier_shift(tm, (2.3, -1.6, 0.0))
+    np.testing.assert_allclose(MO.register_translation_3d(img, tm, 10, max_shifts=(6, 6, 2)), [2.3, -1.6, 0.0], atol=1e-6)
+    # the window: a shift outside max_shifts is not found
+    far = np.roll(tm, 9, axis=0)
+    assert abs(MO.register_translation_3d(far, tm, 1, max_shifts=(6, 6, 2))[0]) < 6
+    # the window around a rigid estimate: [ceil(r - dev), floor(r + dev))
+    s = MO.register_translation_3d(img, tm, 10, shifts_lb=np.array([0, -4, -3]), shifts_ub=np.array([5, 2, 3]), max_shifts=(6, 6, 2))
+    np.testing.assert_allclose(s, [2.3, -1.6, 0.0], atol=1e-6)
+
+
+def test_tile_shifts_and_points():
+    from oracle import motion_oracle as MO
+    tm = smooth_volume((48, 40, 2), 1)
+    video = np.array([tm, fourier_shift(tm, (1.2, 0.7, 0.0)), fourier_shift(tm, (-2.0, 1.5, 0.0))])
+    sx, sy, sz, rig = MO.pw_rigid_shifts(video, tm, (16, 12, 1), (8, 8, 1), (5, 5, 1))
+    np.testing.assert_allclose(rig[1], [1.2, 0.7, 0], atol=1e-6)
+    assert sx.shape == (3, len(MO.sliding_window_3d((48, 40, 2), (8, 8, 1), (16, 12, 1))))
+    # total_shifts = (-x, -y, +z); a small patch of a non-periodic field under-estimates its shift (circular correlation)
+    assert -1.6 < np.median(sx[1]) < -0.5 and -1.9 < np.median(sy[2]) < -0.7
+    pts = np.array([[10.0, 10.0, 0.5], [40.0, 30.0, 1.0]])
+    P_T = MO.apply_shifts_points(sx, sy, sz, (48, 40, 2), (8, 8, 1), (16, 12, 1), pts)
+    assert P_T.shape == (2, 3, 3)
+    np.testing.assert_allclose(P_T[:, :, 0], pts)
+    # a point follows the video: P_T = p - (shift[t] - shift[0]) with shift = -displacement
+    assert 0.4 < P_T[0, 0, 1] - pts[0, 0] < 1.7 and 0.6 < P_T[1, 1, 2] - pts[1, 1] < 2.0
