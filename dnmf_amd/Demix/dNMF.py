@@ -289,6 +289,11 @@ class DeformableNMF:
         # blocks of a footprint row are non-zero, else K3, 'bf16' = K3b (every product, operands rounded to bf16: reduced precision the
         # reference does not have, never chosen by 'auto')
         self.gram_kernel = 'auto'
+        # footprint update (spatial_step): 'lists' = K5 / K6 on (tile, listed neuron) pairs only, 'dense' = the MFMA K5 on all
+        # P x K entries, 'auto' = lists while the footprints are compact
+        self.spatial_kernel = 'auto'
+        self._sl = None
+        self._ws_k5 = None
         # torch.distributed group when this object holds one contiguous T-shard per rank (rank order = frame order);
         # used where the path has a real exchange: the neighbour term of update_temporal and spatial_step
         self.group = None
@@ -361,21 +366,31 @@ class DeformableNMF:
         fp = self.fp
         P, K = fp.P, fp.K
         C = self.C.to(device, torch.float32).contiguous()
-        # A1 and C_s live in one buffer so that the exchange is a single collective
-        if self._spatial_buf is None or self._spatial_buf.numel() != P * K + K * K:
-            self._spatial_buf = torch.empty((P * K + K * K,), dtype=torch.float32, device=device)
-        buf = self._spatial_buf
-        A1, Cs = buf[:P * K].view(P, K), buf[P * K:].view(K, K)
         if times is None:
             times = frame_ids
-        if K <= 128:
-            ops.spatial_accum(registered, C, frame_ids=frame_ids, times=times, A1=A1, Cs=Cs, accumulate=False)
-        else:  # K5 holds 8 trace blocks per wave: columns of A1 by groups of 128 neurons; C C^T is tiny
-            Cl = C[:, :registered.shape[0]] if times is None else C[:, torch.as_tensor(times, device=C.device).long()]
-            for s0 in range(0, K, 128):
-                part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=times)
-                A1[:, s0:s0 + 128] = part
-            Cs.copy_((Cl.double() @ Cl.double().T).float())
+        sl = self._spatial_lists()
+        # A1 and C_s live in one buffer so that the exchange is a single collective; with compact footprints A1 exists
+        # only for (tile, listed neuron) pairs -- a few floats per voxel instead of K (3 MB instead of 105 MB at cfg 3)
+        n1 = sl["total"] if sl is not None else P * K
+        if self._spatial_buf is None or self._spatial_buf.numel() != n1 + K * K:
+            self._spatial_buf = None
+            self._spatial_buf = torch.empty((n1 + K * K,), dtype=torch.float32, device=device)
+        buf = self._spatial_buf
+        Cs = buf[n1:].view(K, K)
+        if sl is not None:
+            A1 = buf[:n1]
+            _, _, self._ws_k5 = ops.spatial_accum_lists(registered, C, sl, fp.sz_list, K, frame_ids=frame_ids, times=times, A1c=A1,
+                                                        Cs=Cs, workspace=getattr(self, "_ws_k5", None))
+        else:
+            A1 = buf[:n1].view(P, K)
+            if K <= 128:
+                ops.spatial_accum(registered, C, frame_ids=frame_ids, times=times, A1=A1, Cs=Cs, accumulate=False)
+            else:  # K5 holds 8 trace blocks per wave: columns of A1 by groups of 128 neurons; C C^T is tiny
+                Cl = C[:, :registered.shape[0]] if times is None else C[:, torch.as_tensor(times, device=C.device).long()]
+                for s0 in range(0, K, 128):
+                    part, _ = ops.spatial_accum(registered, C[s0:s0 + 128].contiguous(), frame_ids=frame_ids, times=times)
+                    A1[:, s0:s0 + 128] = part
+                Cs.copy_((Cl.double() @ Cl.double().T).float())
         if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
             if self.collective == "c1" and torch.distributed.get_backend(self.group) == "nccl":
                 # the library's own RCCL communicator (C1 of the C ABI: what a host without torch would call), built on
@@ -392,10 +407,34 @@ class DeformableNMF:
             if self._D_dev is None or self._D_dev[0] is not D:
                 self._D_dev = (D, torch.as_tensor(D).to(device, torch.float32).reshape(P, K).contiguous())
             Dd = self._D_dev[1]
-        ops.mu_spatial(A2, A1, Cs, Dd, gamma)
+        if sl is not None:
+            ops.mu_spatial_lists(A2, fp.packed_lists(), sl, A1, Cs, fp.sz_list, Dd, gamma)
+        else:
+            ops.mu_spatial(A2, A1, Cs, Dd, gamma)
         fp.A = A2.view(*fp.sz_list, K)
         fp.invalidate_layouts()   # K6 wrote through the raw pointer: the packed copies are stale
+        self._sl = None
         return fp.A
+
+    def _spatial_lists(self):
+        """Tile lists of the list-form footprint update (``ops.spatial_lists_setup``) when ``spatial_kernel`` allows it and
+        the footprints are compact (the rule of the Gram kernel: few boxes per voxel; no tile with more than 32 neurons),
+        else None: dense K5 / K6."""
+        fp = self.fp
+        if self.spatial_kernel not in ('auto', 'lists') or fp.K > 256 or fp.P * 32 >= 2 ** 31 or fp.sz_list[1] * fp.sz_list[2] < 4:
+            return None
+        ly = fp.packed_lists()
+        if self.spatial_kernel == 'auto' and ly["boxfrac"] >= LISTS_BOXFRAC_LIMIT:
+            return None
+        key = (fp.A.data_ptr(), fp.A._version)
+        if getattr(self, "_sl", None) is None or self._sl[0] != key:
+            self._sl = (key, ops.spatial_lists_setup(ly, fp.K, fp.sz_list))
+        sl = self._sl[1]
+        if sl["total"] <= 0:
+            if self.spatial_kernel == 'lists':
+                raise ValueError("spatial_kernel='lists': a tile lists more than 32 neurons (or none at all)")
+            return None
+        return sl
 
     # ---- fit steps -------------------------------------------------------------------------------------
     def _gather_frames(self, loader):

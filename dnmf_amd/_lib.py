@@ -62,6 +62,11 @@ SIGNATURES = {
     "dnmf_motion_grad_lists_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dnmf_motion_grad_lists": (_i, [_vp, _vp, _i, _vp, _l, _vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i,
                                     _vp, _sz, _vp]),
+    "dnmf_spatial_lists_tiles": (_l, [_i, _i, _i]),
+    "dnmf_spatial_lists_setup": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "dnmf_spatial_accum_lists_workspace": (_sz, [_i, _i, _i, _l, _i]),
+    "dnmf_spatial_accum_lists": (_i, [_vp, _l, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
+    "dnmf_mu_spatial_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, _vp]),
     "dnmf_register_patches_grid": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dnmf_register_patches_workspace": (_sz, [_i, _i, _i, _vp, _vp, _i]),
     "dnmf_register_patches": (_i, [_vp, _l, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),

@@ -339,6 +339,59 @@ def mu_spatial(A, A1, Cs, D=None, gamma=0.0):
     return A
 
 
+def spatial_lists_setup(layout, K, sz):
+    """Tile lists of the list-form footprint update from the boxes of ``pack_footprints_lists``: dict(tables int32,
+    total) -- ``total`` floats of the compact A1 buffer, or -1 when a tile lists more than 32 neurons (use the dense K5)."""
+    X, Y, Z = (int(s) for s in sz)
+    lib = _lib.load()
+    nt = lib.dnmf_spatial_lists_tiles(X, Y, Z)
+    tables = torch.empty((2 * nt + 2 + 32 * nt,), dtype=torch.int32, device=layout["bbox"].device)
+    _lib.check(lib.dnmf_spatial_lists_setup(layout["bbox"].data_ptr(), K, X, Y, Z, tables.data_ptr(), _stream()),
+               "dnmf_spatial_lists_setup")
+    return {"tables": tables, "total": int(tables[2 * nt].item()), "ntiles": nt}
+
+
+def spatial_accum_lists(Y, C, sl, sz, K, frame_ids=None, times=None, A1c=None, Cs=None, workspace=None):
+    """K5, list form.  Y (>=T, ldy) registered frames, C (K, ldc) -> A1c (total) compact sums, Cs (K,K)."""
+    X, Yd, Z = (int(s) for s in sz)
+    if Y.dtype != torch.float32 or Y.stride(-1) != 1 or not Y.is_cuda:
+        raise ValueError("spatial_accum_lists: Y must be float32 CUDA with unit inner stride")
+    if C.dtype != torch.float32 or C.stride(-1) != 1 or not C.is_cuda:
+        raise ValueError("spatial_accum_lists: C must be float32 CUDA with unit inner stride")
+    dev = Y.device
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    tt = _i32(times, dev) if times is not None else None
+    T = fid.numel() if fid is not None else (tt.numel() if tt is not None else Y.shape[0])
+    total = sl["total"]
+    if A1c is None:
+        A1c = torch.empty((total,), dtype=torch.float32, device=dev)
+        Cs = torch.empty((K, K), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    need = lib.dnmf_spatial_accum_lists_workspace(X, Yd, Z, total, T)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+    with _timed("spatial_accum_lists"):
+        rc = lib.dnmf_spatial_accum_lists(Y.data_ptr(), Y.stride(0), _ptr(fid), C.data_ptr(), C.stride(0), _ptr(tt), T, X, Yd, Z, K,
+                                          sl["tables"].data_ptr(), total, A1c.data_ptr(), Cs.data_ptr(), _ptr(workspace),
+                                          0 if workspace is None else workspace.numel() * workspace.element_size(), _stream())
+    _lib.check(rc, "dnmf_spatial_accum_lists")
+    return A1c, Cs, workspace
+
+
+def mu_spatial_lists(A, layout, sl, A1c, Cs, sz, D=None, gamma=0.0):
+    """K6, list form: A (P,K) updated in place at the entries the tiles list; A1c is overwritten with the new values."""
+    X, Y, Z = (int(s) for s in sz)
+    for t, n in ((A, "A"), (A1c, "A1c"), (Cs, "Cs")):
+        _f32(t, n)
+    if D is not None:
+        _f32(D, "D")
+    with _timed("mu_spatial_lists"):
+        rc = _lib.load().dnmf_mu_spatial_lists(A.data_ptr(), layout["At"].data_ptr(), A1c.data_ptr(), Cs.data_ptr(), _ptr(D),
+                                               float(gamma or 0.0), X, Y, Z, A.shape[1], sl["tables"].data_ptr(), _stream())
+    _lib.check(rc, "dnmf_mu_spatial_lists")
+    return A
+
+
 def pack_footprints_lists(A, sz):
     """Layout of K3n: dict(At (K,P), bbox (K,6) int32, pair_slot (K,K) int32, nslot int, boxfrac) -- ``boxfrac`` is
     the summed volume of the footprint boxes over the volume, i.e. the mean number of listed neurons per voxel."""

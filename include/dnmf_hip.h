@@ -318,6 +318,25 @@ int dnmf_render_frames(const float *positions, const double *traces, int K, int 
                        int Y, int Z, double shape_std, double amp_max, float *out, long ldo,
                        dnmf_stream_t stream);
 
+/* ---- K5 / K6, list form (compact footprints) ---------------------------------------------------------------------
+ * Reference: DeformableNMF.update_spatial, Demix/dNMF.py:151-160 -- A1 = Y_i C^T is only ever used multiplied by A, which is
+ * an exact zero outside footprint k's non-zero box and stays zero under the update.  Tiles of 4 x-rows x 64 positions of the
+ * (y,z) plane list the neurons whose box (bbox of dnmf_pack_footprints_lists) meets them; the sums exist only for (tile,
+ * listed neuron) pairs, in a compact buffer A1c of `total` floats (1 KiB per pair) -- also what the ranks all-reduce.
+ * tables: int[2 ntiles + 2 + 32 ntiles], ntiles = dnmf_spatial_lists_tiles: list lengths, entry offsets (tables[2 ntiles] =
+ * total, -1 when a tile lists more than 32 neurons: use the dense kernels), an overflow counter, the lists.
+ * dnmf_spatial_accum_lists: A1c and Cs = C C^T (float64 sums) over the T frames given (rows frame_ids[b] or b of Y, trace
+ * columns times[b] or b).  dnmf_mu_spatial_lists: A1c in = the (all-reduced) sums, out = the new footprint values; A (P,K) is
+ * updated in place at the listed entries (every other entry is and stays zero); At = the neuron-major halo copy of A. */
+long dnmf_spatial_lists_tiles(int X, int Y, int Z);
+int dnmf_spatial_lists_setup(const int *bbox, int K, int X, int Y, int Z, int *tables, dnmf_stream_t stream);
+size_t dnmf_spatial_accum_lists_workspace(int X, int Y, int Z, long total, int T);
+int dnmf_spatial_accum_lists(const float *Y, long ldy, const int *frame_ids, const float *C, long ldc, const int *times, int T, int X,
+                             int Yd, int Z, int K, const int *tables, long total, float *A1c, float *Cs, void *workspace,
+                             size_t workspace_bytes, dnmf_stream_t stream);
+int dnmf_mu_spatial_lists(float *A, const float *At, float *A1c, const float *Cs, const float *D, double gamma, int X, int Y, int Z,
+                          int K, const int *tables, dnmf_stream_t stream);
+
 /* ---- K8: position initialiser ----------------------------------------------------------------------
  * Reference: Demix/MotionCorrect.py -- MotionCorrect.motion_correct_pwrigid :260-328 -> tile_and_correct_3d :1518-1608
  * (per frame: rigid shift, then one shift per patch inside rigid +- max_deviation_rigid; register_translation_3d :648-797 with

@@ -696,3 +696,53 @@ def test_motion_grad_in_pieces_is_the_same_gradient(M):
                          gamma=1, epochs=2)
         res.append(dn.fp.beta.detach().clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("sz", [[64, 48, 2], [37, 30, 1], [21, 9, 3]])
+def test_list_form_of_the_footprint_update(M, O, sz):
+    """K5 / K6 in their list form (sums only for the (tile, listed neuron) pairs whose box meets the tile) against the dense
+    kernels and against the oracle's update_spatial (reference Demix/dNMF.py:151-160) on compact footprints: identical
+    zero pattern (a zero stays a zero), the new values equal to the dense path's to the rounding of the frame sums (1e-5)
+    and to the oracle's float64 result; with and without D; plane sizes that are and are not multiples of four voxels;
+    through a frame-index indirection.  A tile with more than 32 neurons sends 'auto' back to the dense kernels."""
+    from dnmf_amd import ops
+    rng = np.random.RandomState(sum(sz))
+    K, T = 14, 70
+    P = int(np.prod(sz))
+    pos = rng.rand(K, 3) * np.array(sz)
+    A = O.gaussian_footprints(sz, pos, np.full(K, 1.2))
+    A[A < 1e-5] = 0
+    frames = torch.rand(T + 5, P, device="cuda")
+    rows = torch.randperm(T + 5)[:T].to(torch.int32).cuda()
+    C0 = (0.2 + rng.rand(K, T)).astype(np.float32)
+    D = rng.rand(*sz, K)
+    res = {}
+    for kernel in ("dense", "lists"):
+        for use_D in (False, True):
+            dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(pos).float())
+            dn.verbose = False
+            dn.fp.A = dev(A)
+            dn.C = dev(C0)
+            dn.spatial_kernel = kernel
+            res[kernel, use_D] = dn.spatial_step(frames, D=D if use_D else None, gamma=0.3 if use_D else None, frame_ids=rows,
+                                                 times=torch.arange(T, dtype=torch.int32)).cpu().numpy().astype(np.float64)
+            if kernel == "lists" and P >= 4096:   # (tiles are padded to 256 voxels: tiny volumes gain nothing)
+                assert dn._spatial_buf.numel() < P * K // 2 + K * K          # the exchanged buffer is the compact one
+    Yi = frames[rows.long()].cpu().numpy().astype(np.float64).T.reshape(sz[0], sz[1] * sz[2], T)
+    for use_D in (False, True):
+        want = O.update_spatial(A.astype(np.float64).reshape(sz[0], sz[1] * sz[2], K), C0.astype(np.float64), Yi,
+                                D=D.reshape(sz[0], sz[1] * sz[2], K) if use_D else None, gamma=0.3 if use_D else None).reshape(*sz, K)
+        got = res["lists", use_D]
+        assert np.array_equal(got != 0, A != 0)
+        np.testing.assert_allclose(got, res["dense", use_D], rtol=1e-5, atol=1e-30)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-30)
+    # every neuron in one place: the tile holds more than 32 of them
+    Kc = 40
+    dn = M.DeformableNMF(torch.tensor([32, 32, 2]), Kc, 8, positions=torch.tensor([[16.0, 16.0, 1.0]]).repeat(Kc, 1))
+    dn.fp.A = dn.fp.A * (dn.fp.A > 1e-3)
+    assert ops.spatial_lists_setup(dn.fp.packed_lists(), Kc, [32, 32, 2])["total"] == -1
+    dn.fp.use_lists = False
+    dn.spatial_step(torch.rand(8, 2048, device="cuda"))                      # 'auto' -> dense
+    dn.spatial_kernel = "lists"
+    with pytest.raises(ValueError):
+        dn.spatial_step(torch.rand(8, 2048, device="cuda"))
