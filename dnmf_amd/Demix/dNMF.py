@@ -320,19 +320,35 @@ class DeformableNMF:
     def update_temporal(A_t, C, Y, gamma=None):
         """One multiplicative update of ``C`` given explicit warped footprints (reference :139-149).
         ``A_t`` (X,Y,Z,K,T), ``C`` (K,T), ``Y`` (X,Y,Z,T) numpy; returns float64 numpy (K,T).  The contraction runs on
-        the fp32 matrix cores (K3 without a warp: every voxel's own row of ``A_t``), the update in float64 (K4); at
-        most 127 neurons per call (one K3 launch)."""
+        the fp32 matrix cores (K3 without a warp: every voxel's own row of ``A_t``), the update in float64 (K4); more than
+        127 neurons go by pairs of neuron groups (one K3 launch holds 127)."""
         A_t, C, Y = np.asarray(A_t), np.asarray(C), np.asarray(Y)
         X, Y_, Z, K, T = A_t.shape
-        if K > 127:
-            raise ValueError(f"update_temporal (static): K={K} > 127 neurons; use DeformableNMF.update_footprints, which "
-                             "cuts the neurons into groups")
         P = X * Y_ * Z
         dev = torch.device(device)
         A_dev = torch.from_numpy(np.ascontiguousarray(np.moveaxis(A_t, 4, 0).reshape(T, P, K))).to(dev, torch.float32)
-        Apk = ops.pack_footprints(A_dev)                                   # (T*P, Kp)
         frames = torch.from_numpy(np.ascontiguousarray(np.moveaxis(Y, 3, 0).reshape(T, P))).to(dev, torch.float32)
-        G, r, _ = ops.warp_gram_rhs(Apk, K, (X, Y_, Z), None, list(range(T)), frames, a_frame_stride=P * Apk.shape[1])
+
+        def gram(cols):
+            sub = A_dev if cols is None else A_dev[:, :, cols].contiguous()
+            Apk = ops.pack_footprints(sub)                                 # (T*P, Kp)
+            return ops.warp_gram_rhs(Apk, sub.shape[2], (X, Y_, Z), None, list(range(T)), frames,
+                                     a_frame_stride=P * Apk.shape[1])[:2]
+
+        if K <= 127:
+            G, r = gram(None)
+        else:
+            # one K3 launch holds 127 neurons: groups of 56, every PAIR of groups one launch on their union (both diagonal
+            # blocks and the off-diagonal block of the pair), as DeformableNMF._gram_rhs_grouped does on the fit path
+            G = torch.empty((T, K, K), dtype=torch.float32, device=dev)
+            r = torch.empty((T, K), dtype=torch.float32, device=dev)
+            groups = [list(range(s0, min(K, s0 + 56))) for s0 in range(0, K, 56)]
+            for i in range(len(groups)):
+                for j in range(i + 1, len(groups)):
+                    idx = torch.as_tensor(groups[i] + groups[j], device=dev)
+                    Gp, rp = gram(idx)
+                    G[:, idx[:, None], idx[None, :]] = Gp
+                    r[:, idx] = rp
         return _mu_temporal(G, r, torch.from_numpy(np.asarray(C, dtype=np.float64)).to(dev), gamma, 1).cpu().numpy()
 
     @staticmethod
@@ -948,8 +964,49 @@ class MultiChannelDNMF(DeformableNMF):
         return super().update_footprints(testloader, batch_size, sz, gamma_c=gamma_c, gamma_a=gamma_a, iter_c=iter_c,
                                          return_dense=False)
 
-    def spatial_step(self, *a, **k):
-        raise NotImplementedError("MultiChannelDNMF.spatial_step")
+    def spatial_step(self, registered, D=None, gamma=None, frame_ids=None, times=None):
+        """One multiplicative update of the (uncoloured) footprints ``fp.A`` from the registered frames of ALL channels
+        (rows of NC * P floats).  With channel c showing neuron k as ``colours[c,k] A[:,k]`` the update of the shared ``A``
+        that the reference's formula (``Demix/dNMF.py:151-160``) becomes is
+
+            A <- A * (sum_c colours_c (Y_i^c C^T)) / (A (C C^T * colours^T colours) + gamma D + 1e-32)
+
+        (numerator: K5 per channel, scaled by the channel's colours; denominator: K6 with C_s multiplied entry by entry by
+        the Gram matrix of the colours).  One all-reduce of the A1 | C_s buffer over ``self.group`` like the single-channel
+        step.  Not in the reference (no channel axis there): checked against this formula in float64 and, for one channel of
+        colour 1, against ``DeformableNMF.spatial_step``."""
+        fp = self.fp
+        P, K = fp.P, fp.K
+        NC = self.colours.shape[0]
+        if registered.shape[1] != NC * P:
+            raise ValueError(f"MultiChannelDNMF.spatial_step: rows of {registered.shape[1]} floats, expected {NC} x {P}")
+        if K > 128:
+            raise NotImplementedError("MultiChannelDNMF.spatial_step: K > 128")
+        C = self.C.to(device, torch.float32).contiguous()
+        if times is None:
+            times = frame_ids
+        if self._spatial_buf is None or self._spatial_buf.numel() != P * K + K * K:
+            self._spatial_buf = None
+            self._spatial_buf = torch.empty((P * K + K * K,), dtype=torch.float32, device=device)
+        buf = self._spatial_buf
+        A1, Cs = buf[:P * K].view(P, K), buf[P * K:].view(K, K)
+        A1.zero_()
+        for c in range(NC):
+            part, cs = ops.spatial_accum(registered[:, c * P:(c + 1) * P], C, frame_ids=frame_ids, times=times)
+            A1.addcmul_(part, self.colours[c][None, :])
+            if c == 0:
+                Cs.copy_(cs)
+        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
+            with ops._timed("allreduce"):
+                torch.distributed.all_reduce(buf, group=self.group)
+        Cs.mul_(self.colours.T @ self.colours)
+        A2 = fp.A.reshape(P, K).contiguous()
+        Dd = None if D is None else torch.as_tensor(D).to(device, torch.float32).reshape(P, K).contiguous()
+        ops.mu_spatial(A2, A1, Cs, Dd, gamma)
+        fp.A = A2.view(*fp.sz_list, K)
+        fp.invalidate_layouts()
+        self._chan_fp = None
+        return fp.A
 
 
 def _mu_temporal(G, r, C, gamma, iters, group=None, nbr=None):
@@ -1133,7 +1190,9 @@ class NeuroPALVideoDataset(Dataset):
     """Reference ``Demix/dNMF.py:220-248``: a recorded video (``data.mat``: ``data`` (X,Y,Z,T)) with tracked
     neuron positions (``traces_n.mat``: ``positions`` (K,3,T), 1-based; ``neuron_names``).  Same fixed
     sub-sampling as the reference (every 2nd voxel in x and y, every 10th in z, the first 100 frames); paths are
-    joined portably (the reference hard-codes Windows separators)."""
+    joined portably (the reference hard-codes Windows separators).  The bodies of ``__init__`` and ``__getitem__`` restate
+    reference ``Demix/dNMF.py:221-248`` almost line for line (``os.path.join`` instead of ``'\\'``): the file format, the
+    sub-sampling and the rescaling of the positions are the interface, there is nothing to redesign in them."""
 
     def __init__(self, file):
         import os

@@ -106,10 +106,14 @@ def test_bench_path_vs_fixture_G9(M, O, monkeypatch, label, passes):
     np.testing.assert_allclose(dn.C.cpu().numpy(), g[label + "_C_after_footprints"], rtol=1e-4)
 
 
-def test_bench_path_vs_oracle_config1(M, O, monkeypatch):
+@pytest.mark.parametrize("lr", [1e-5, 1e-4])
+def test_bench_path_vs_oracle_config1(M, O, monkeypatch, lr):
     """BASELINE configs[0] geometry (64x64, K=10, simulator video), two outer iterations of the demo loop with
     shuffled mini-batches through the bench's path, against the CPU oracle run on the same batch order -- the
-    resident / fused counterpart of test_gpu_parity.py::test_config1_like_run_vs_oracle, same tolerances."""
+    resident / fused counterpart of test_gpu_parity.py::test_config1_like_run_vs_oracle.  With the demo's Adam step
+    (lr = 1e-5, demo.py:42) every trace stays in range and EVERY row is compared at rtol 1e-3; with ten times that step
+    the warps drift by voxels within the two iterations, traces whose footprint has lost its neuron run away in the
+    reference's own update (oracle and HIP path alike), and only the calm rows can be compared (5e-3)."""
     torch.manual_seed(0)
     np.random.seed(0)
     sz, K, T, bs = [64, 64, 2], 10, 24, 4
@@ -119,12 +123,12 @@ def test_bench_path_vs_oracle_config1(M, O, monkeypatch):
     gen = torch.Generator().manual_seed(3)
     orders = [[torch.randperm(T, generator=gen).tolist() for _ in range(2)] for _ in range(2)]
     ref = O.OracleModel(sz, K, T, positions[:, :, 0], C0=C0.numpy())
-    ropt = torch.optim.Adam([ref.beta_param], lr=1e-4)
+    ropt = torch.optim.Adam([ref.beta_param], lr=lr)
     dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(positions[:, :, 0]))
     dn.verbose = False
     dn.fp.A = dev(ref.A)
     dn.C = C0.to("cuda")
-    opt = torch.optim.Adam([dn.fp.beta], lr=1e-4)
+    opt = torch.optim.Adam([dn.fp.beta], lr=lr)
     frames = dev(np.moveaxis(video, 3, 0)).reshape(T, -1)
     calls = Calls(monkeypatch, "adam_epoch", "warp_gram_rhs_lists")
     test = M.ResidentLoader(frames, sz, bs)
@@ -140,6 +144,10 @@ def test_bench_path_vs_oracle_config1(M, O, monkeypatch):
     disp = np.abs(ref.beta - ident).max()
     np.testing.assert_allclose(dn.fp.beta.detach().cpu().numpy() - ident, ref.beta - ident, rtol=0, atol=1e-2 * disp)
     got, want = dn.C.cpu().numpy(), ref.C
+    if lr <= 1e-5:
+        assert want.max() < 10
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6)
+        return
     calm = want.max(1) < 10   # see test_config1_like_run_vs_oracle: the reference's own update runs away for some rows
     assert calm.sum() >= 3
     np.testing.assert_allclose(got[calm], want[calm], rtol=5e-3, atol=1e-6)
@@ -595,8 +603,41 @@ def test_static_update_temporal_takes_A_t_as_it_is(M, O, sz):
         got = M.DeformableNMF.update_temporal(A_t, C, Y, gamma=gamma)
         want = O.update_temporal(A_t, C, Y, gamma=gamma)
         np.testing.assert_allclose(got, want, rtol=2e-5)
-    with pytest.raises(ValueError):
-        M.DeformableNMF.update_temporal(rng.rand(2, 2, 1, 128, 1), rng.rand(128, 1), rng.rand(2, 2, 1, 1))
+    # more than 127 neurons: by pairs of neuron groups (the reference has no limit, Demix/dNMF.py:139-149)
+    Kb = 130
+    A_t, C, Y = rng.rand(6, 5, 2, Kb, 2), 0.3 + rng.rand(Kb, 2), rng.rand(6, 5, 2, 2)
+    np.testing.assert_allclose(M.DeformableNMF.update_temporal(A_t, C, Y), O.update_temporal(A_t, C, Y), rtol=2e-5)
+
+
+def test_multichannel_spatial_step(M):
+    """MultiChannelDNMF.spatial_step (not in the reference: channels are extra voxels that share beta and C, and channel c
+    shows neuron k as colours[c,k] A[:,k]): against the update formula in float64, and for ONE channel of colour 1 against
+    DeformableNMF.spatial_step bit for bit (dense kernels)."""
+    rng = np.random.RandomState(4)
+    sz, K, T, NC = [20, 16, 2], 9, 12, 3
+    P = int(np.prod(sz))
+    pos = torch.from_numpy(rng.rand(K, 3) * np.array(sz)).float()
+    colours = torch.from_numpy(0.3 + rng.rand(NC, K)).float()
+    frames = torch.rand(T, NC * P, device="cuda")
+    C0 = dev(0.2 + rng.rand(K, T))
+    D = rng.rand(*sz, K)
+    dn = M.MultiChannelDNMF(torch.tensor(sz), K, T, colours, positions=pos)
+    dn.C = C0.clone()
+    A0 = dn.fp.A.reshape(P, K).double().cpu().numpy()
+    got = dn.spatial_step(frames, D=D, gamma=0.2).reshape(P, K).double().cpu().numpy()
+    Cn, col = C0.double().cpu().numpy(), colours.double().numpy()
+    Y = frames.double().cpu().numpy().reshape(T, NC, P)
+    A1 = sum(col[c][None, :] * (Y[:, c].T @ Cn.T) for c in range(NC))
+    den = A0 @ ((Cn @ Cn.T) * (col.T @ col)) + 0.2 * D.reshape(P, K) + 1e-32
+    np.testing.assert_allclose(got, A0 * A1 / den, rtol=3e-5, atol=1e-30)
+    one = M.MultiChannelDNMF(torch.tensor(sz), K, T, torch.ones(1, K), positions=pos)
+    one.C = C0.clone()
+    ref = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    ref.C = C0.clone()
+    ref.spatial_kernel = "dense"
+    a = one.spatial_step(frames[:, :P].contiguous(), D=D, gamma=0.2)
+    b = ref.spatial_step(frames[:, :P].contiguous(), D=D, gamma=0.2)
+    assert torch.equal(a, b)
 
 
 def test_short_adam_epoch_is_torch_bit_for_bit(M):
