@@ -27,15 +27,15 @@ constexpr int IW_TILE = 1024;
 constexpr int IW_RMAX = 24;   // largest window radius searched in place (49 x 49 (x Z) candidates)
 
 // warped position of voxel (x,y,z) scaled by sz (not sz-1), fp32 like the reference (flow_ is a float32 tensor there)
-template <bool HASZ>
+template <bool HASZ, int FAST = -1>
 __device__ __forceinline__ void iwarp_position_t(const float *bt, const Volume &vol, int x, int y, int z, float &sx,
                                                  float &sy, float &sz) {
     const float xf = (float)x, yf = (float)y, zf = HASZ ? (float)z : 0.0f;
-    const float nx = grid_n<HASZ>(bt, vol, 0, xf, yf, zf);
-    const float ny = grid_n<HASZ>(bt, vol, 1, xf, yf, zf);
+    const float nx = grid_n<HASZ, FAST>(bt, vol, 0, xf, yf, zf);
+    const float ny = grid_n<HASZ, FAST>(bt, vol, 1, xf, yf, zf);
     sx = __fmul_rn(__fmul_rn(__fadd_rn(nx, 1.0f), 0.5f), (float)vol.X);
     sy = __fmul_rn(__fmul_rn(__fadd_rn(ny, 1.0f), 0.5f), (float)vol.Y);
-    sz = HASZ ? __fmul_rn(__fmul_rn(__fadd_rn(grid_n<HASZ>(bt, vol, 2, xf, yf, zf), 1.0f), 0.5f), (float)vol.Z) : 0.0f;
+    sz = HASZ ? __fmul_rn(__fmul_rn(__fadd_rn(grid_n<HASZ, FAST>(bt, vol, 2, xf, yf, zf), 1.0f), 0.5f), (float)vol.Z) : 0.0f;
 }
 __device__ __forceinline__ void iwarp_position(const float *bt, const Volume &vol, int x, int y, int z, float &sx, float &sy,
                                                float &sz) {
@@ -180,10 +180,35 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
         const long idx = ((long)x * vol.Y + yy) * vol.Z + z;
         if (d < best || (d == best && idx < arg)) best = d, arg = idx;   // ties: the lowest voxel index, as in the full search
     };
-    // (an axis of one voxel names its only candidate twice; the second comparison changes nothing)
+    // The cell's corners are ranked by their fp32 squared distances first (round 3).  The float64 comparison of the reference
+    // (on the same fp32 positions) can only order two candidates differently from the fp32 ranking when their fp32 distances
+    // are within a few roundings of each other (relative 2e-6 here; the fp32 evaluation's error is below 4e-7): only then
+    // are the float64 distances formed -- e.g. at the identity of a Z > 1 volume, where every point has two equidistant
+    // candidates (:83 scales by sz, not sz - 1).  (An axis of one voxel names its only candidate twice: harmless.)
+    constexpr int NC = HASZ ? 8 : 4;
+    float d1 = __builtin_inff(), d2 = __builtin_inff();   // smallest and second smallest fp32 squared distance
+    int i1 = 0;
 #pragma unroll
-    for (int i = 0; i < (HASZ ? 8 : 4); ++i)
-        candidate((i & (HASZ ? 4 : 2)) ? c1[0] : c0[0], (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1], (HASZ && (i & 1)) ? c1[2] : c0[2]);
+    for (int i = 0; i < (HASZ ? 0 : NC); ++i) {
+        float sx, sy, sz;
+        iwarp_position_t<HASZ>(bt, vol, (i & (HASZ ? 4 : 2)) ? c1[0] : c0[0], (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1],
+                               (HASZ && (i & 1)) ? c1[2] : c0[2], sx, sy, sz);
+        const float dx = sx - gf[0], dy = sy - gf[1], dz = sz - gf[2];
+        const float d = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        const bool lt = d < d1;
+        d2 = lt ? d1 : fminf(d2, d);
+        i1 = lt ? i : i1;
+        d1 = lt ? d : d1;
+    }
+    if (!HASZ && d2 > d1 * 1.000002f + 1e-30f) {   // a clear winner (Z > 1: fits start at the identity, where all points tie)
+        const int x = (i1 & (HASZ ? 4 : 2)) ? c1[0] : c0[0], yy = (i1 & (HASZ ? 2 : 1)) ? c1[1] : c0[1], z = (HASZ && (i1 & 1)) ? c1[2] : c0[2];
+        arg = ((long)x * vol.Y + yy) * vol.Z + z;
+        best = (double)d1;
+    } else {                              // near tie (or NaN): decide in float64, lowest voxel index among equals
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            candidate((i & (HASZ ? 4 : 2)) ? c1[0] : c0[0], (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1], (HASZ && (i & 1)) ? c1[2] : c0[2]);
+    }
     // fp32 rounding of the positions (lattice and continuous evaluation): a few units in the last place at magnitudes
     // up to the volume size; the radius itself is evaluated in fp32, rounded generously upwards
     const float eps = 1e-4f + 1e-5f * (float)max(vol.X, max(vol.Y, vol.Z));
@@ -200,12 +225,141 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
         hi[d] = d < ND ? min((int)floorf(v[d] + r), S[d] - 1) : 0;
         inside = inside && lo[d] >= c0[d] && hi[d] <= c1[d];
     }
-    if (!inside)
+    if (!inside) {
+        best = 1e300, arg = 0;   // the whole box in float64 (r >= 1 here: it contains the cell)
         for (int x = lo[0]; x <= hi[0]; ++x)
             for (int yy = lo[1]; yy <= hi[1]; ++yy)
                 for (int z = lo[2]; z <= hi[2]; ++z) candidate(x, yy, z);
+    }
     out[(long)b * ldo + g] = y[arg];
     *flag = 0;
+}
+
+// Z == 1, round 3: the window search with a thread that walks IW_ROWS consecutive rows x at a fixed y.  Same arithmetic and
+// the same certificate as image_iwarp_window_kernel<false>, organised so that the per-thread costs are shared: the thirty
+// coefficients are loaded and doubled once per IW_ROWS lattice points; the pre-image of the next row starts from the last
+// one moved by one row (one fixed-point step instead of two); and the cell of the next row usually sits on top of the last
+// one, so two of its four corner positions are already known.  Points that need more than their cell (or a frame without
+// a usable stretch bound) are handled exactly as there: the box in float64, or a mark for the exhaustive kernel.
+#ifndef DNMF_IW_ROWS
+#define DNMF_IW_ROWS 8
+#endif
+constexpr int IW_ROWS = DNMF_IW_ROWS;
+
+template <int FAST>
+__global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__restrict__ frames, long ldf,
+                                                               const int *__restrict__ frame_ids, Volume vol,
+                                                               const float *__restrict__ beta, int T, const int *__restrict__ times,
+                                                               const float *__restrict__ inv_stretch, IwarpScale sc,
+                                                               float *__restrict__ out, long ldo, unsigned char *__restrict__ todo,
+                                                               unsigned *__restrict__ marked, int nyb) {
+    const int b = blockIdx.y;
+    const int yb = blockIdx.x % nyb, xb = blockIdx.x / nyb;
+    const int gy = yb * 256 + threadIdx.x;
+    if (gy >= vol.Y) return;
+    const int x_first = xb * IW_ROWS, x_end = min(x_first + IW_ROWS, vol.X);
+    const float inv_m = inv_stretch[b];
+    auto mark = [&](unsigned char *flag) {
+        *flag = 1;
+        const unsigned long long mm = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm)) atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm));
+    };
+    if (!(inv_m < 1e3f)) {
+        for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (long)gx * vol.Y + gy);
+        return;
+    }
+    const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
+    float bt[30], b2[30];
+    load_beta(beta, T, times[b], bt);
+    double_beta(bt, b2);
+    const float k[2] = {sc.k[0], sc.k[1]}, hk[2] = {sc.hk[0], sc.hk[1]};
+    const float eps = 1e-4f + 1e-5f * (float)max(vol.X, vol.Y);
+    const float gyf = (float)gy;
+    float v[2] = {(float)x_first * k[0], gyf * k[1]};
+    // corner positions kept from the last row: those of voxel row `kept_x` at columns kept_y, kept_y + 1
+    int kept_x = -1000, kept_y = -1000;
+    float kept[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [column][sx, sy]
+    for (int gx = x_first; gx < x_end; ++gx) {
+        const long g = (long)gx * vol.Y + gy;
+        unsigned char *flag = todo + (long)b * vol.P + g;
+        const float gf[2] = {(float)gx, gyf};
+        float res[2];
+        auto residual = [&]() {
+            const Monomials<false> mo = monomials<false>(v[0], v[1], 0.0f);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) res[d] = gf[d] - poly_a<false>(b2, d, mo) * hk[d];
+        };
+        // fixed-point steps towards the pre-image: two from scratch, one from the last row's pre-image moved by a row
+        const int steps = gx == x_first ? 2 : 1;
+        for (int it = 0; it < steps; ++it) {
+            residual();
+            v[0] += res[0] * k[0], v[1] += res[1] * k[1];
+        }
+        float vc[2] = {fminf(fmaxf(v[0], 0.0f), (float)(vol.X - 1)), fminf(fmaxf(v[1], 0.0f), (float)(vol.Y - 1))};
+        {
+            const float keep0 = v[0], keep1 = v[1];
+            v[0] = vc[0], v[1] = vc[1];
+            residual();
+            v[0] = keep0 + k[0], v[1] = keep1;    // the next row starts here
+        }
+        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1]);
+        const int c0x = min((int)vc[0], max(vol.X - 2, 0)), c1x = min(c0x + 1, vol.X - 1);
+        const int c0y = min((int)vc[1], max(vol.Y - 2, 0)), c1y = min(c0y + 1, vol.Y - 1);
+        // the four corners: row c0x from the last row's upper corners when they are the same voxels
+        float px[2][2][2];   // [row][column][sx, sy]
+        const bool reuse = kept_x == c0x && kept_y == c0y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sz;
+            if (reuse)
+                px[0][j][0] = kept[j][0], px[0][j][1] = kept[j][1];
+            else
+                iwarp_position_t<false, FAST>(bt, vol, c0x, j ? c1y : c0y, 0, px[0][j][0], px[0][j][1], sz);
+            iwarp_position_t<false, FAST>(bt, vol, c1x, j ? c1y : c0y, 0, px[1][j][0], px[1][j][1], sz);
+            kept[j][0] = px[1][j][0], kept[j][1] = px[1][j][1];
+        }
+        kept_x = c1x, kept_y = c0y;
+        float d1 = __builtin_inff(), d2 = __builtin_inff();
+        int i1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dx = px[i >> 1][i & 1][0] - gf[0], dy = px[i >> 1][i & 1][1] - gf[1];
+            const float d = fmaf(dx, dx, dy * dy);
+            const bool lt = d < d1;
+            d2 = lt ? d1 : fminf(d2, d);
+            i1 = lt ? i : i1;
+            d1 = lt ? d : d1;
+        }
+        double best = (double)d1;
+        long arg = (long)((i1 >> 1) ? c1x : c0x) * vol.Y + ((i1 & 1) ? c1y : c0y);
+        auto candidate = [&](int x, int yy) {
+            float sx, sy, sz;
+            iwarp_position_t<false, FAST>(bt, vol, x, yy, 0, sx, sy, sz);
+            const double dx = (double)sx - gx, dy = (double)sy - gy;
+            const double d = dx * dx + dy * dy;
+            const long idx = (long)x * vol.Y + yy;
+            if (d < best || (d == best && idx < arg)) best = d, arg = idx;
+        };
+        if (!(d2 > d1 * 1.000002f + 1e-30f)) {   // near tie (or NaN): the four in float64, lowest voxel index among equals
+            best = 1e300, arg = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) candidate((i >> 1) ? c1x : c0x, (i & 1) ? c1y : c0y);
+        }
+        const float r = ((sqrtf((float)best) + rho) * 1.00001f + 3.0f * eps) * inv_m + 1e-3f;
+        if (!(r < (float)IW_RMAX)) {   // also NaN
+            mark(flag);
+            continue;
+        }
+        const int lox = max((int)ceilf(vc[0] - r), 0), hix = min((int)floorf(vc[0] + r), vol.X - 1);
+        const int loy = max((int)ceilf(vc[1] - r), 0), hiy = min((int)floorf(vc[1] + r), vol.Y - 1);
+        if (!(lox >= c0x && hix <= c1x && loy >= c0y && hiy <= c1y)) {
+            best = 1e300, arg = 0;   // the whole box in float64 (r >= 1 here: it contains the cell)
+            for (int x = lox; x <= hix; ++x)
+                for (int yy = loy; yy <= hiy; ++yy) candidate(x, yy);
+        }
+        out[(long)b * ldo + g] = y[arg];
+        *flag = 0;
+    }
 }
 
 // The exhaustive search (P candidates per lattice point, tiles of warped positions in LDS) for the marked points.
@@ -311,9 +465,16 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
         if (Z > 1)
             hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
                                times, stretch, sc, out, ldo, todo, marked);
-        else
-            hipLaunchKernelGGL(image_iwarp_window_kernel<false>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
-                               times, stretch, sc, out, ldo, todo, marked);
+        else {
+            const int nyb = (Y + 255) / 256;
+            const dim3 rgrid((unsigned)(nyb * ((X + IW_ROWS - 1) / IW_ROWS)), (unsigned)B);
+            if (vol.fastdiv)
+                hipLaunchKernelGGL(image_iwarp_rows_kernel<1>, rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,
+                                   stretch, sc, out, ldo, todo, marked, nyb);
+            else
+                hipLaunchKernelGGL(image_iwarp_rows_kernel<0>, rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,
+                                   stretch, sc, out, ldo, todo, marked, nyb);
+        }
     }
     if (fallback_count && marked) {
         hipLaunchKernelGGL(sum_marked_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, marked, B, fallback_count);
