@@ -24,7 +24,8 @@
 namespace dnmf {
 
 constexpr int IW_TILE = 1024;
-constexpr int IW_RMAX = 24;   // largest window radius searched in place (49 x 49 (x Z) candidates)
+constexpr int IW_RMAX = 64;   // largest window radius searched in place (129 x 129 (x Z) candidates: lattice points near the
+                              // border whose pre-image lies ~25 voxels outside the volume; beyond that the exhaustive kernel)
 
 // warped position of voxel (x,y,z) scaled by sz (not sz-1), fp32 like the reference (flow_ is a float32 tensor there)
 template <bool HASZ, int FAST = -1>
@@ -96,6 +97,7 @@ __global__ void iwarp_stretch_kernel(const float *__restrict__ beta, int T, cons
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     marked[b] = 0;
+    if (b == 0) marked[B] = 0;   // marked[B]: frames of this call with a marked point
     float bt[30];
     load_beta(beta, T, times[b], bt);
     const double m = iwarp_min_stretch(bt, vol);
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
     auto mark = [&]() {
         *flag = 1;
         const unsigned long long mm = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm)) atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm));
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm) && atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm)) == 0)
+            atomicAdd(&marked[gridDim.y], 1u);   // (gridDim.y = the frames of the call)
     };
     const float inv_m = inv_stretch[b];
     if (!(inv_m < 1e3f)) {
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
     auto mark = [&](unsigned char *flag) {
         *flag = 1;
         const unsigned long long mm = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm)) atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm));
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm) && atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm)) == 0)
+            atomicAdd(&marked[gridDim.y], 1u);   // (gridDim.y = the frames of the call)
     };
     if (!(inv_m < 1e3f)) {
         for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (long)gx * vol.Y + gy);
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(256) void image_iwarp_full_kernel(const float *__re
     if (g < vol.P) voxel_xyz(g, vol, gx, gy, gz);
     // the frames b = blockIdx.y, + gridDim.y, ...: a frame without marked points costs one scalar load (a block per frame
     // and tile that only looked at the counter was 1.1 ms of launches per 4000 frames at 512x512)
+    if (marked && marked[B] == 0) return;         // nothing marked in the whole call (the usual case): one scalar load
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         if (marked && marked[b] == 0) continue;   // block-uniform
         const bool mine = g < vol.P && todo[(long)b * vol.P + g];
@@ -429,7 +434,7 @@ static size_t iwarp_flag_bytes(int X, int Y, int Z, int B) { return ((size_t)X *
 
 size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B) {
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
-    return iwarp_flag_bytes(X, Y, Z, B) + (sizeof(float) + sizeof(unsigned)) * (size_t)B;
+    return iwarp_flag_bytes(X, Y, Z, B) + (sizeof(float) + sizeof(unsigned)) * (size_t)B + sizeof(unsigned);
 }
 
 int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta, int T,
