@@ -592,14 +592,12 @@ def main():
 
         def roofs_spatial(r):
             out = []
-            k7 = r["evs"]("image_iwarp")
-            if k7:
-                out.append(hbm_roof("image_iwarp kernels (K7: nearest warped voxel of every lattice point)",
-                                    1e3 * sum(k7) / len(k7), 8.0 * P * T_loc, "frames read 4PT + registered frames written 4PT"))
+            if r["per_step_ms"].get("image_iwarp"):   # (several launches per sweep: the flag bytes of a launch are bounded)
+                out.append(hbm_roof("image_iwarp kernels (K7: nearest warped voxel of every lattice point), all launches of a sweep",
+                                    r["per_step_ms"]["image_iwarp"], 8.0 * P * T_loc, "frames read 4PT + registered frames written 4PT"))
             for name in ("spatial_accum", "spatial_accum_lists"):
-                k5 = r["evs"](name)
-                if k5:
-                    out.append(hbm_roof(f"{name} (K5: A1 = Y_i C^T over the frames)", 1e3 * sum(k5) / len(k5),
+                if r["per_step_ms"].get(name):
+                    out.append(hbm_roof(f"{name} (K5: A1 = Y_i C^T over the frames)", r["per_step_ms"][name],
                                         4.0 * P * T_loc + 4.0 * K * T_loc + 4.0 * P * K,
                                         "registered frames 4PT + traces 4KT read, A1 4PK written"))
             return out
