@@ -388,7 +388,7 @@ def sharded_footprint_update(dn, frames, sz, bs, iter_c, group, world, updates=2
     check = dn.fp.A.double().sum().reshape(1)
     sums = [torch.zeros_like(check) for _ in range(world)]
     dist.all_gather(sums, check, group=group)
-    nbytes = 4 * (P * K + K * K)
+    nbytes = 4 * dn._spatial_buf.numel()   # A1c | C_s: the compact buffer when the footprints are compact, else P K + K^2 floats
     return {"what": "update_footprints(live_spatial=True) on every rank: K3n + K4, K7, K5, one all-reduce (sum) of A1 | C_s, K6",
             "backend": "torch.distributed 'nccl' = RCCL" if dist.get_backend(group) == "nccl" else f"torch.distributed '{dist.get_backend(group)}'",
             "ranks": world,
