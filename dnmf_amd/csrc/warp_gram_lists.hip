@@ -71,6 +71,12 @@ typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef DNMF_K3N_WAVES
 #define DNMF_K3N_WAVES 4   // waves per SIMD the Z == 1 kernel is compiled for (128 registers)
 #endif
+#ifndef DNMF_K3N_DMA
+#define DNMF_K3N_DMA 1   // 1: the regions of a list go from global memory straight into LDS (global_load_lds), all of them
+#endif                   // requested ahead of the tile's coordinate arithmetic, through no registers (round 3: 3.14 -> 2.91 ms)
+#ifndef DNMF_K3N_DMA2
+#define DNMF_K3N_DMA2 1  // the same for the two groups of a long list (second launch)
+#endif
 #ifndef DNMF_K3N_WAVES_Z2
 #define DNMF_K3N_WAVES_Z2 4   // the same for Z == 2
 #endif
@@ -498,10 +504,41 @@ __global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS =
         // latency (3.10 -> 3.05 ms per 4000 frames at 512x512, K=100).  Eight registers in flight fit; the first TWO
         // neurons' regions (sixteen) spill: 3.98 ms.  Z == 1 only: with the third coordinate chain of Z == 2 in flight the
         // eight registers are not there (151 registers wanted against 131 without).
-        constexpr bool EARLY = DNMF_K3N_EARLY1 && PASS == 1 && ZM == 1;
+        constexpr bool DMA = DNMF_K3N_DMA && ZM != 3;
+        constexpr bool EARLY = DNMF_K3N_EARLY1 && PASS == 1 && ZM == 1 && !DMA;
+        // the short list (PASS 1: it came with the tile's descriptor; the one-kernel form reads it off the mask words)
+        int ks[LISTS_NG];
+#pragma unroll
+        for (int i = 0; i < LISTS_NG; ++i) ks[i] = -1;
+        if (PASS == 1) {
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i) ks[i] = i < n ? (int)(((unsigned)ids >> (8 * i)) & 0xffu) : -1;
+        } else if (PASS == 0 && n <= LISTS_NG) {
+            unsigned long long rem[NW];
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
+            take_ids(rem, ks);
+        }
         f32x4 early[2];
         if (EARLY && staged) {
             stage_load((int)((unsigned)ids & 0xffu), early);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // LDS-DMA: neuron k's region into staging slot i without passing through registers (piece e = lane + 64 j lands at
+        // byte 16 e of the slot: the DMA writes lane l's 16 bytes at base + 16 l)
+        auto stage_dma = [&](int k, int i) {
+            const char *__restrict__ Ak = reinterpret_cast<const char *>(p.At) + (size_t)k * plane + reg_goff;
+            auto dst = (__attribute__((address_space(3))) char *)(stage_lds + i * (LISTS_REGION * 4));
+            __builtin_amdgcn_global_load_lds(Ak + (unsigned)(piece_row[0] * hl.row4 + piece_c4[0] * 16), dst, 16, 0, 0);
+            if (lane + 64 < LISTS_REGION / 4)
+                __builtin_amdgcn_global_load_lds(Ak + (unsigned)(piece_row[1] * hl.row4 + piece_c4[1] * 16), dst + 1024, 16, 0, 0);
+        };
+        if (DMA && PASS != 2 && staged && n <= LISTS_NG) {
+            // (the last tile's reads of the slots have long returned: their values went into its sums)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < LISTS_NG; ++i)
+                if (i < n) stage_dma(ks[i], i);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -677,21 +714,18 @@ __global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS =
         n_eval += n, n_pair += n * (n + 1) / 2;
         if (PASS != 2 && n <= LISTS_NG) {
             // the usual case: the whole list in registers; sums join the pending run (same list) or start one
-            int ks[LISTS_NG];
-            if (PASS == 1) {   // the list came with the tile's descriptor
-#pragma unroll
-                for (int i = 0; i < LISTS_NG; ++i) ks[i] = i < n ? (int)(((unsigned)ids >> (8 * i)) & 0xffu) : -1;
-            } else {
-                unsigned long long rem[NW];
-#pragma unroll
-                for (int wd = 0; wd < NW; ++wd) rem[wd] = msk[wd];
-                take_ids(rem, ks);
-            }
             const bool fresh = run_n == 0;
             auto go = [&](auto nn) {
                 constexpr int N = decltype(nn)::value;
                 float a[N][LISTS_VPL];
-                if (staged) {
+                if (staged && DMA) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the regions (and the frame values) have landed
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        eval_staged(i, a[i]);
+                        if (HASZ) __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (staged) {
                     // the regions are requested two neurons at a time (four would hold 32 registers for the pieces)
 #pragma unroll
                     for (int i0 = 0; i0 < N; i0 += 2) {
@@ -766,13 +800,20 @@ __global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS =
             take_ids(rem, kB);
             const int nB = n - LISTS_NG;
             float aA[LISTS_NG][LISTS_VPL], aB[LISTS_NG][LISTS_VPL];
+            if (DMA && DNMF_K3N_DMA2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
-                f32x4 piece[2][2];
+                for (int i = 0; i < LISTS_NG; ++i) stage_dma(kA[i], i);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
 #pragma unroll
-                for (int i = i0; i < i0 + 2; ++i) stage_load(kA[i], piece[i - i0]);
+                for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
+                    f32x4 piece[2][2];
 #pragma unroll
-                for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+                    for (int i = i0; i < i0 + 2; ++i) stage_load(kA[i], piece[i - i0]);
+#pragma unroll
+                    for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < LISTS_NG; ++i) {
@@ -791,14 +832,22 @@ __global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS =
                 run_n = LISTS_NG;
                 flush();
             }
+            if (DMA && DNMF_K3N_DMA2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // group A's values are in registers
 #pragma unroll
-            for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
-                if (i0 >= nB) break;   // wave-uniform
-                f32x4 piece[2][2];
+                for (int i = 0; i < LISTS_NG; ++i)
+                    if (i < nB) stage_dma(kB[i], i);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
 #pragma unroll
-                for (int i = i0; i < i0 + 2; ++i) stage_load(max(kB[i], 0), piece[i - i0]);   // past the list: neuron 0, unused
+                for (int i0 = 0; i0 < LISTS_NG; i0 += 2) {
+                    if (i0 >= nB) break;   // wave-uniform
+                    f32x4 piece[2][2];
 #pragma unroll
-                for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+                    for (int i = i0; i < i0 + 2; ++i) stage_load(max(kB[i], 0), piece[i - i0]);   // past the list: neuron 0, unused
+#pragma unroll
+                    for (int i = i0; i < i0 + 2; ++i) stage_store(i, piece[i - i0]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < LISTS_NG; ++j) {
