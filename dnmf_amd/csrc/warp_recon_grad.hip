@@ -26,6 +26,10 @@ constexpr int K2_NACC = 32;           // 30 gradient sums + squared error + pad
 #ifndef DNMF_K2_UNROLL_Z
 #define DNMF_K2_UNROLL_Z 1
 #endif
+#ifndef DNMF_K2_REUSE
+#define DNMF_K2_REUSE 1   // the lower tap row from the last voxel's upper one when the whole wave steps by one row
+#endif
+constexpr bool K2_REUSE = DNMF_K2_REUSE != 0;
 #ifndef DNMF_K2_WAVES_Z
 #define DNMF_K2_WAVES_Z 1
 #endif
@@ -127,7 +131,11 @@ __global__ __launch_bounds__(256, (ZM > 1 ? DNMF_K2_WAVES_Z : 1)) void warp_reco
         unsigned u4 = (unsigned)u * (4u * NV);
         // ZC: the voxel's slice when it is known at compile time (Z == 2: 0 or 1), else -1.  z == 0: the four terms with z
         // add an exact zero each (the Z == 1 chain); z == 1: their monomials are 1, 1, x, y.
-        auto taps = [&](const float2 xv, float xy, auto zc, Vox &q) {
+        unsigned prev_o[NV];
+        float prev_v[NV][HASZ ? 4 : 2];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) prev_o[v] = 0xffffffffu;
+        auto taps = [&](const float2 xv, float xy, auto zc, int slot, Vox &q) {
             constexpr int ZC = decltype(zc)::value;
             float a[3] = {0.0f, 0.0f, 0.0f};
             if constexpr (ZC == 0) {
@@ -177,22 +185,46 @@ __global__ __launch_bounds__(256, (ZM > 1 ? DNMF_K2_WAVES_Z : 1)) void warp_reco
                     zo = (unsigned)izc * 4u;
                 }
             }
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                unsigned o = o0 + (ZM == 3 ? zo : 0u) + (dx ? (unsigned)hl.row4 : 0u);   // (scalar base + 32-bit offset) loads
+            // The tap row dx = 0 of this voxel is the tap row dx = 1 of the thread's last voxel whenever the warp moves the
+            // base corner by exactly one row between consecutive x (every near-identity warp): when that holds for all lanes of
+            // the wave the values are still in registers and only the upper row is gathered -- the kernel is bound by the
+            // gather path (TA 97 % busy at Z = 1, 79 % at Z = 2: misaligned 8 / 16-byte gathers, ~16 cycles per
+            // wave-instruction), this halves its load for such warps: Z = 1 1.95 -> 1.72 ms per 4000 frames at 512x512 in the
+            // bench, 4.6 TB/s -> 5.05 TB/s = what a device copy reaches.  Z >= 2 is bound by instruction issue instead: the
+            // test and the moves cost it 8 % (4.66 -> 5.05 ms), so it is Z == 1 only.  Same bytes either way.
+            constexpr int NT = HASZ ? 4 : 2;
+            const unsigned olo = o0 + (ZM == 3 ? zo : 0u), ohi = olo + (unsigned)hl.row4;
+            auto gather = [&](unsigned o, float (&v)[NT]) {
                 asm("" : "+v"(o));
-                const char *t = s + o;
+                const char *t = s + o;   // (scalar base + 32-bit offset) loads
                 if constexpr (ZM == 2) {          // (y, z0), (y, z1), (y + 1, z0), (y + 1, z1): one load, 8-byte aligned
-                    const f32x4_a8 v = *reinterpret_cast<const f32x4_a8 *>(t);
-                    q.sv[0][0][dx] = v.x, q.sv[1][0][dx] = v.y, q.sv[0][1][dx] = v.z, q.sv[1][1][dx] = v.w;
+                    const f32x4_a8 r = *reinterpret_cast<const f32x4_a8 *>(t);
+                    v[0] = r.x, v[1] = r.y, v[2] = r.z, v[3] = r.w;
                 } else if constexpr (ZM == 3) {   // the z-pair of corner y, then of corner y + 1
-                    const f32x2_a4 v0 = *reinterpret_cast<const f32x2_a4 *>(t);
-                    const f32x2_a4 v1 = *reinterpret_cast<const f32x2_a4 *>(t + hl.col4);
-                    q.sv[0][0][dx] = v0.x, q.sv[1][0][dx] = v0.y, q.sv[0][1][dx] = v1.x, q.sv[1][1][dx] = v1.y;
+                    const f32x2_a4 r0 = *reinterpret_cast<const f32x2_a4 *>(t);
+                    const f32x2_a4 r1 = *reinterpret_cast<const f32x2_a4 *>(t + hl.col4);
+                    v[0] = r0.x, v[1] = r0.y, v[2] = r1.x, v[3] = r1.y;
                 } else {
-                    q.sv[0][0][dx] = *reinterpret_cast<const float *>(t);
-                    q.sv[0][1][dx] = *reinterpret_cast<const float *>(t + 4);
+                    v[0] = *reinterpret_cast<const float *>(t);
+                    v[1] = *reinterpret_cast<const float *>(t + 4);
                 }
+            };
+            float lo[NT], hi[NT];
+            if (K2_REUSE && (ZM == 1 || DNMF_K2_REUSE > 1) && __ballot(olo != prev_o[slot]) == 0) {   // wave-uniform
+#pragma unroll
+                for (int i = 0; i < NT; ++i) lo[i] = prev_v[slot][i];
+            } else {
+                gather(olo, lo);
+            }
+            gather(ohi, hi);
+            prev_o[slot] = ohi;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) prev_v[slot][i] = hi[i];
+            if constexpr (HASZ) {
+                q.sv[0][0][0] = lo[0], q.sv[1][0][0] = lo[1], q.sv[0][1][0] = lo[2], q.sv[1][1][0] = lo[3];
+                q.sv[0][0][1] = hi[0], q.sv[1][0][1] = hi[1], q.sv[0][1][1] = hi[2], q.sv[1][1][1] = hi[3];
+            } else {
+                q.sv[0][0][0] = lo[0], q.sv[0][1][0] = lo[1], q.sv[0][0][1] = hi[0], q.sv[0][1][1] = hi[1];
             }
         };
         auto request = [&](int x, Req &q) {
@@ -202,12 +234,12 @@ __global__ __launch_bounds__(256, (ZM > 1 ? DNMF_K2_WAVES_Z : 1)) void warp_reco
             asm("" : "+v"(u4));
             const char *op = reinterpret_cast<const char *>((!PLAIN && go ? go : y) + q.prow) + u4;
             if constexpr (ZPAIR) {
-                taps(q.xv, xy, std::integral_constant<int, 0>{}, q.v[0]);
-                taps(q.xv, xy, std::integral_constant<int, 1>{}, q.v[1]);
+                taps(q.xv, xy, std::integral_constant<int, 0>{}, 0, q.v[0]);
+                taps(q.xv, xy, std::integral_constant<int, 1>{}, NV - 1, q.v[1]);
                 const float2 o2 = *reinterpret_cast<const float2 *>(op);   // (x, y, 0), (x, y, 1): eight aligned bytes
                 q.v[0].other = o2.x, q.v[NV - 1].other = o2.y;
             } else {
-                taps(q.xv, xy, std::integral_constant<int, -1>{}, q.v[0]);
+                taps(q.xv, xy, std::integral_constant<int, -1>{}, 0, q.v[0]);
                 q.v[0].other = *reinterpret_cast<const float *>(op);
             }
         };
