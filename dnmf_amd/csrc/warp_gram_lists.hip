@@ -95,7 +95,10 @@ constexpr long LISTS_ITEMS = 16384;  // target number of wave-sized work items p
 constexpr int LISTS_MAX_SLOTS = 3800;  // 4 waves x 3800 words of LDS per workgroup
 // Staged gathers (Z == 1): the taps of an 8 x 32 tile lie in a region of RR rows x RC floats of a footprint image; a wave
 // copies that region of each listed neuron into LDS with sixteen-byte loads and gathers from there (see the kernel).
-constexpr int LISTS_RR = 12, LISTS_RC = 40;                 // 9 tap rows + slack; 33 tap columns + alignment of the first + slack
+#ifndef DNMF_K3N_RR
+#define DNMF_K3N_RR 12
+#endif
+constexpr int LISTS_RR = DNMF_K3N_RR, LISTS_RC = 40;                 // 9 tap rows + slack; 33 tap columns + alignment of the first + slack
 constexpr int LISTS_REGION = LISTS_RR * LISTS_RC;            // floats per neuron: 1,920 bytes, 120 sixteen-byte pieces
 static_assert(LISTS_RC % 4 == 0 && LISTS_REGION / 4 <= 128 && LISTS_REGION / 4 > 64, "stage_load moves two pieces per lane");
 
