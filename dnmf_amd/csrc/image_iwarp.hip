@@ -19,6 +19,9 @@
 // kernel, the O(P) per point search of round 1.  Both kernels evaluate s(voxel) with the same fp32 sequence and
 // compare the same float64 distances, lowest voxel index first among equals, so the result is the exhaustive search's
 // bit for bit (the rounding of s in fp32 is covered by a slack in the radius).
+// Round 3 sharpened the radius twice (both in image_iwarp_rows_kernel, which serves every volume with X, Y > 1): per-axis
+// radii from the linear part of s for Z > 1 (iwarp_min_stretch), and a bound of |s(v*) - s(v)| by the angle between that
+// vector and g - s(v), which settles the lattice points whose pre-image left the volume without a box.
 #include "common.hpp"
 
 namespace dnmf {
@@ -49,7 +52,19 @@ __device__ __forceinline__ void iwarp_position(const float *bt, const Volume &vo
 // Lower bound of |q(a) - q(b)| / |a - b| over the volume for the quadratic map q = basis . beta (the un-scaled warp;
 // s = q S/(S-1) stretches every axis by a factor >= 1, so the bound holds for s as well): smallest singular value of
 // the Jacobian at the centre minus the largest change of the Jacobian over the volume (Frobenius norm).
-__device__ double iwarp_min_stretch(const float *b, const Volume &vol) {
+// `an` (Z > 1 only; round 3) receives the constants of the ANISOTROPIC radii, all of the linear map M = D J(centre), D =
+// diag(S/(S-1)): s(v*) - s(v) = M (v* - v) + E (v* - v) with |E|_F <= max(D) drift, hence |M (v* - v)| <= R (1 +
+// max(D) drift / m) =: R' for R = d0 + rho.  With n the unit normal of the image of the (x, y) plane, mu = |n . M_z|,
+// t = M_z - (n . M_z) n and m2 = the smallest singular value of [M_x M_y]:
+//   |v*_z - v_z| <= R' / mu                                (the component of M (v* - v) along n is (n . M_z)(v*_z - v_z))
+//   |(v* - v)_xy| <= (sqrt(R'^2 - (mu delta)^2) + |t| R' / mu) / m2      for delta <= |v*_z - v_z|
+// and a lattice point is at least delta = |v_z - round(v_z)| away from v in z.  At the reference's depth (Z = 2, D_z = 2)
+// the odd slice lies one voxel from both slice images (d0 = 1, the isotropic radius 1.02: a box of 18 voxels for every
+// point), but mu delta = 1 as well: the (x, y) radius is ~0.2 and the box is the cell again.
+// an = {mu (rounded down), |t| (up), 1 / m2 (up), 1 + max(D) drift / m (up)}; {0, 0, inf, inf} when there is none.
+// an[4..14] (any Z): max(D) drift (up), |M|_F (up), M row by row (z row and column zero for Z == 1) -- see the rows kernel.
+constexpr int IW_NK = 16;   // floats per frame: 1/m, then an[0..14]
+__device__ double iwarp_min_stretch(const float *b, const Volume &vol, float *an = nullptr) {
     const bool hz = vol.Z > 1;
     const int nd = hz ? 3 : 2;
     const double cx = 0.5 * (vol.X - 1), cy = 0.5 * (vol.Y - 1), cz = hz ? 0.5 * (vol.Z - 1) : 0.0;
@@ -87,11 +102,50 @@ __device__ double iwarp_min_stretch(const float *b, const Volume &vol) {
     }
     const double drift = cx * sqrt(hx) + cy * sqrt(hy) + cz * sqrt(hzz);
     const double m = 0.98 * (smin - drift);
+    if (an) {
+        an[0] = 0.0f, an[1] = 0.0f, an[2] = __builtin_inff(), an[3] = __builtin_inff();
+        const double D[3] = {vol.X / (vol.X - 1.0), vol.Y / (vol.Y - 1.0), hz ? vol.Z / (vol.Z - 1.0) : 1.0};
+        const double dmax = fmax(D[0], fmax(D[1], D[2]));
+        double M[3][3], mf = 0;
+        for (int d = 0; d < 3; ++d)
+            for (int e = 0; e < 3; ++e) {
+                M[d][e] = (d < nd && e < nd) ? D[d] * J[d][e] : 0.0;
+                mf += M[d][e] * M[d][e];
+                an[6 + 3 * d + e] = (float)M[d][e];
+            }
+        an[4] = (float)(dmax * drift) * 1.000001f + 1e-30f;
+        an[5] = (float)sqrt(mf) * 1.000001f;
+        if (!(an[4] < 1e6f && an[5] < 1e6f)) an[4] = an[5] = __builtin_inff();   // (NaN too)
+        if (hz && m > 1e-3) {
+            double n[3] = {M[1][0] * M[2][1] - M[2][0] * M[1][1], M[2][0] * M[0][1] - M[0][0] * M[2][1],
+                           M[0][0] * M[1][1] - M[1][0] * M[0][1]};   // M_x x M_y
+            const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            const double ga = M[0][0] * M[0][0] + M[1][0] * M[1][0] + M[2][0] * M[2][0],
+                         gc = M[0][1] * M[0][1] + M[1][1] * M[1][1] + M[2][1] * M[2][1],
+                         gb = M[0][0] * M[0][1] + M[1][0] * M[1][1] + M[2][0] * M[2][1];
+            const double lmin = 0.5 * (ga + gc - sqrt((ga - gc) * (ga - gc) + 4.0 * gb * gb));
+            if (nn > 1e-6 && lmin > 1e-6) {
+                for (int d = 0; d < 3; ++d) n[d] /= nn;
+                const double nz = n[0] * M[0][2] + n[1] * M[1][2] + n[2] * M[2][2];
+                double t2 = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const double t = M[d][2] - nz * n[d];
+                    t2 += t * t;
+                }
+                const double vals[4] = {fabs(nz) * (1.0 - 1e-6), sqrt(t2) * (1.0 + 1e-6) + 1e-12, (1.0 + 1e-6) / sqrt(lmin),
+                                        (1.0 + dmax * drift / m) * (1.0 + 1e-6)};
+                bool ok = vals[0] > 1e-3;
+                for (int i = 0; i < 4; ++i) ok = ok && vals[i] == vals[i] && vals[i] < 1e6;
+                if (ok)
+                    for (int i = 0; i < 4; ++i) an[i] = (float)vals[i] * (i == 0 ? 0.999999f : 1.000001f);
+            }
+        }
+    }
     return m == m ? m : 0.0;   // NaN coefficients: no bound
 }
 
 // 1/m of every frame of the call, rounded up; +inf where there is no usable bound (every point of such a frame is
-// then marked for the exhaustive search)
+// then marked for the exhaustive search); then the constants of the sharper radii (IW_NK floats per frame in all)
 __global__ void iwarp_stretch_kernel(const float *__restrict__ beta, int T, const int *__restrict__ times, int B, Volume vol,
                                      float *__restrict__ inv_stretch, unsigned *__restrict__ marked) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,8 +154,11 @@ __global__ void iwarp_stretch_kernel(const float *__restrict__ beta, int T, cons
     if (b == 0) marked[B] = 0;   // marked[B]: frames of this call with a marked point
     float bt[30];
     load_beta(beta, T, times[b], bt);
-    const double m = iwarp_min_stretch(bt, vol);
-    inv_stretch[b] = m > 1e-3 ? (float)(1.0 / m) * 1.000001f : __builtin_inff();
+    float an[IW_NK - 1];
+    const double m = iwarp_min_stretch(bt, vol, an);
+    inv_stretch[IW_NK * b] = m > 1e-3 ? (float)(1.0 / m) * 1.000001f : __builtin_inff();
+#pragma unroll
+    for (int i = 0; i < IW_NK - 1; ++i) inv_stretch[IW_NK * b + 1 + i] = an[i];
 }
 
 struct IwarpScale {
@@ -131,7 +188,7 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
         if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm) && atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm)) == 0)
             atomicAdd(&marked[gridDim.y], 1u);   // (gridDim.y = the frames of the call)
     };
-    const float inv_m = inv_stretch[b];
+    const float inv_m = inv_stretch[IW_NK * b];
     if (!(inv_m < 1e3f)) {
         mark();
         return;
@@ -238,131 +295,273 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
     *flag = 0;
 }
 
-// Z == 1, round 3: the window search with a thread that walks IW_ROWS consecutive rows x at a fixed y.  Same arithmetic and
-// the same certificate as image_iwarp_window_kernel<false>, organised so that the per-thread costs are shared: the thirty
+// Round 3: the window search with a thread that walks IW_ROWS consecutive rows x at a fixed (y, z).  Same arithmetic and
+// the same certificate as image_iwarp_window_kernel, organised so that the per-thread costs are shared: the thirty
 // coefficients are loaded and doubled once per IW_ROWS lattice points; the pre-image of the next row starts from the last
 // one moved by one row (one fixed-point step instead of two); and the cell of the next row usually sits on top of the last
-// one, so two of its four corner positions are already known.  Points that need more than their cell (or a frame without
-// a usable stretch bound) are handled exactly as there: the box in float64, or a mark for the exhaustive kernel.
+// one, so half of its corner positions (two of four, four of eight) are already known.  The corners are ranked by their
+// fp32 squared distances first: the float64 comparison of the reference (on the same fp32 positions) can only order two
+// candidates differently from the fp32 ranking when their fp32 distances are within a few roundings of each other
+// (relative 2e-6 here; the fp32 evaluation's error is below 4e-7), so float64 distances are formed only for the
+// candidates within that margin of the smallest -- two of eight at the identity of a Z == 2 volume, where every lattice
+// point of the odd slice is equidistant from both slices (:83 scales by sz, not sz - 1); lowest voxel index among equals.
+// Points that need more than their cell (or a frame without a usable stretch bound) are handled exactly as in the window
+// kernel: the box in float64, or a mark for the exhaustive kernel.
 #ifndef DNMF_IW_ROWS
 #define DNMF_IW_ROWS 8
 #endif
 constexpr int IW_ROWS = DNMF_IW_ROWS;
+#ifndef DNMF_IW_SHARE
+#define DNMF_IW_SHARE 8
+#endif
+constexpr int IW_SHARE = DNMF_IW_SHARE;   // lanes of a wave whose boxes the wave searches together
 
-template <int FAST>
+template <bool HASZ, int FAST>
 __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__restrict__ frames, long ldf,
                                                                const int *__restrict__ frame_ids, Volume vol,
                                                                const float *__restrict__ beta, int T, const int *__restrict__ times,
                                                                const float *__restrict__ inv_stretch, IwarpScale sc,
                                                                float *__restrict__ out, long ldo, unsigned char *__restrict__ todo,
                                                                unsigned *__restrict__ marked, int nyb) {
+    constexpr int ND = HASZ ? 3 : 2;
+    constexpr int NC = HASZ ? 8 : 4;     // cell corners, index = 4 (x corner) + 2 (y corner) + (z corner) for Z > 1, 2 (x) + (y) else
+    constexpr int NF = NC / 2;           // corners of one x-face
     const int b = blockIdx.y;
     const int yb = blockIdx.x % nyb, xb = blockIdx.x / nyb;
-    const int gy = yb * 256 + threadIdx.x;
-    if (gy >= vol.Y) return;
+    const int YZ = vol.Y * vol.Z;
+    const int u_raw = yb * 256 + threadIdx.x;      // position in the (y, z) plane
+    const bool valid = u_raw < YZ;                 // (lanes past the plane compute the last position and store nothing: the
+    const int u = valid ? u_raw : YZ - 1;          // wave stays whole for the shared box search below)
+    const int gy = HASZ ? div_small(u, vol.Z, vol.rcp_z) : u, gz = HASZ ? u - gy * vol.Z : 0;
     const int x_first = xb * IW_ROWS, x_end = min(x_first + IW_ROWS, vol.X);
-    const float inv_m = inv_stretch[b];
+    const float inv_m = inv_stretch[IW_NK * b];
+    const float *an = inv_stretch + IW_NK * b + 1;
+    const float an_mu = HASZ ? an[0] : 0.0f, an_imu = HASZ ? 1.0f / an[0] : 0.0f, an_t = HASZ ? an[1] : 0.0f,
+                an_im2 = HASZ ? an[2] : 0.0f, an_df = HASZ ? an[3] : 0.0f;
+
     auto mark = [&](unsigned char *flag) {
         *flag = 1;
         const unsigned long long mm = __ballot(1);
         if ((int)(threadIdx.x & 63) == __builtin_ctzll(mm) && atomicAdd(&marked[b], (unsigned)__builtin_popcountll(mm)) == 0)
             atomicAdd(&marked[gridDim.y], 1u);   // (gridDim.y = the frames of the call)
     };
-    if (!(inv_m < 1e3f)) {
-        for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (long)gx * vol.Y + gy);
+    if (!(inv_m < 1e3f)) {   // (block-uniform)
+        if (valid)
+            for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (long)gx * YZ + u);
         return;
     }
     const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
     float bt[30], b2[30];
     load_beta(beta, T, times[b], bt);
     double_beta(bt, b2);
-    const float k[2] = {sc.k[0], sc.k[1]}, hk[2] = {sc.hk[0], sc.hk[1]};
-    const float eps = 1e-4f + 1e-5f * (float)max(vol.X, vol.Y);
-    const float gyf = (float)gy;
-    float v[2] = {(float)x_first * k[0], gyf * k[1]};
-    // corner positions kept from the last row: those of voxel row `kept_x` at columns kept_y, kept_y + 1
-    int kept_x = -1000, kept_y = -1000;
-    float kept[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [column][sx, sy]
+    const float k[3] = {sc.k[0], sc.k[1], sc.k[2]}, hk[3] = {sc.hk[0], sc.hk[1], sc.hk[2]};
+    const int S[3] = {vol.X, vol.Y, vol.Z};
+    const int lane = (int)(threadIdx.x & 63);
+    const float eps = 1e-4f + 1e-5f * (float)max(vol.X, max(vol.Y, vol.Z));
+    float v[3] = {(float)x_first * k[0], (float)gy * k[1], HASZ ? (float)gz * k[2] : 0.0f};
+    // corner positions kept from the last row: the upper x-face of its cell (voxel row kept_x, columns kept_y / + 1, slices
+    // kept_z / + 1)
+    int kept_x = -1000, kept_y = -1000, kept_z = -1000;
+    float kept[NF][3];
     for (int gx = x_first; gx < x_end; ++gx) {
-        const long g = (long)gx * vol.Y + gy;
+        const long g = (long)gx * YZ + u;
         unsigned char *flag = todo + (long)b * vol.P + g;
-        const float gf[2] = {(float)gx, gyf};
-        float res[2];
+        const float gf[3] = {(float)gx, (float)gy, (float)gz};
+        float res[3] = {0.0f, 0.0f, 0.0f};
         auto residual = [&]() {
-            const Monomials<false> mo = monomials<false>(v[0], v[1], 0.0f);
+            const Monomials<HASZ> mo = monomials<HASZ>(v[0], v[1], v[2]);
 #pragma unroll
-            for (int d = 0; d < 2; ++d) res[d] = gf[d] - poly_a<false>(b2, d, mo) * hk[d];
+            for (int d = 0; d < ND; ++d) res[d] = gf[d] - poly_a<HASZ>(b2, d, mo) * hk[d];
         };
         // fixed-point steps towards the pre-image: two from scratch, one from the last row's pre-image moved by a row
         const int steps = gx == x_first ? 2 : 1;
         for (int it = 0; it < steps; ++it) {
             residual();
-            v[0] += res[0] * k[0], v[1] += res[1] * k[1];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) v[d] += res[d] * k[d];
         }
-        float vc[2] = {fminf(fmaxf(v[0], 0.0f), (float)(vol.X - 1)), fminf(fmaxf(v[1], 0.0f), (float)(vol.Y - 1))};
+        float vc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int d = 0; d < ND; ++d) vc[d] = fminf(fmaxf(v[d], 0.0f), (float)(S[d] - 1));
         {
-            const float keep0 = v[0], keep1 = v[1];
-            v[0] = vc[0], v[1] = vc[1];
+            float keep[3] = {v[0], v[1], v[2]};
+#pragma unroll
+            for (int d = 0; d < ND; ++d) v[d] = vc[d];
             residual();
-            v[0] = keep0 + k[0], v[1] = keep1;    // the next row starts here
+            v[0] = keep[0] + k[0], v[1] = keep[1], v[2] = keep[2];    // the next row starts here
         }
-        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1]);
-        const int c0x = min((int)vc[0], max(vol.X - 2, 0)), c1x = min(c0x + 1, vol.X - 1);
-        const int c0y = min((int)vc[1], max(vol.Y - 2, 0)), c1y = min(c0y + 1, vol.Y - 1);
-        // the four corners: row c0x from the last row's upper corners when they are the same voxels
-        float px[2][2][2];   // [row][column][sx, sy]
-        const bool reuse = kept_x == c0x && kept_y == c0y;
+        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
+        int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float sz;
-            if (reuse)
-                px[0][j][0] = kept[j][0], px[0][j][1] = kept[j][1];
-            else
-                iwarp_position_t<false, FAST>(bt, vol, c0x, j ? c1y : c0y, 0, px[0][j][0], px[0][j][1], sz);
-            iwarp_position_t<false, FAST>(bt, vol, c1x, j ? c1y : c0y, 0, px[1][j][0], px[1][j][1], sz);
-            kept[j][0] = px[1][j][0], kept[j][1] = px[1][j][1];
-        }
-        kept_x = c1x, kept_y = c0y;
-        float d1 = __builtin_inff(), d2 = __builtin_inff();
-        int i1 = 0;
+        for (int d = 0; d < ND; ++d) c0[d] = min((int)vc[d], max(S[d] - 2, 0)), c1[d] = min(c0[d] + 1, S[d] - 1);
+        // the corners: the lower x-face from the last row's upper one when they are the same voxels
+        float pos[NC][3];
+        const bool reuse = kept_x == c0[0] && kept_y == c0[1] && kept_z == c0[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dx = px[i >> 1][i & 1][0] - gf[0], dy = px[i >> 1][i & 1][1] - gf[1];
-            const float d = fmaf(dx, dx, dy * dy);
-            const bool lt = d < d1;
-            d2 = lt ? d1 : fminf(d2, d);
-            i1 = lt ? i : i1;
-            d1 = lt ? d : d1;
+        for (int j = 0; j < NF; ++j) {
+            const int yy = (j & (HASZ ? 2 : 1)) ? c1[1] : c0[1], zz = (HASZ && (j & 1)) ? c1[2] : c0[2];
+            if (reuse) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pos[j][d] = kept[j][d];
+            } else {
+                iwarp_position_t<HASZ, FAST>(bt, vol, c0[0], yy, zz, pos[j][0], pos[j][1], pos[j][2]);
+            }
+            iwarp_position_t<HASZ, FAST>(bt, vol, c1[0], yy, zz, pos[NF + j][0], pos[NF + j][1], pos[NF + j][2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) kept[j][d] = pos[NF + j][d];
         }
-        double best = (double)d1;
-        long arg = (long)((i1 >> 1) ? c1x : c0x) * vol.Y + ((i1 & 1) ? c1y : c0y);
-        auto candidate = [&](int x, int yy) {
-            float sx, sy, sz;
-            iwarp_position_t<false, FAST>(bt, vol, x, yy, 0, sx, sy, sz);
-            const double dx = (double)sx - gx, dy = (double)sy - gy;
-            const double d = dx * dx + dy * dy;
-            const long idx = (long)x * vol.Y + yy;
-            if (d < best || (d == best && idx < arg)) best = d, arg = idx;
+        kept_x = c1[0], kept_y = c0[1], kept_z = c0[2];
+        auto corner_index = [&](int i) {
+            const int x = (i >= NF) ? c1[0] : c0[0], yy = (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1], zz = (HASZ && (i & 1)) ? c1[2] : c0[2];
+            return ((long)x * vol.Y + yy) * vol.Z + zz;
         };
-        if (!(d2 > d1 * 1.000002f + 1e-30f)) {   // near tie (or NaN): the four in float64, lowest voxel index among equals
-            best = 1e300, arg = 0;
+        float dist[NC];
+        float d1 = __builtin_inff();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) candidate((i >> 1) ? c1x : c0x, (i & 1) ? c1y : c0y);
+        for (int i = 0; i < NC; ++i) {
+            const float dx = pos[i][0] - gf[0], dy = pos[i][1] - gf[1], dz = HASZ ? pos[i][2] - gf[2] : 0.0f;
+            dist[i] = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            d1 = fminf(d1, dist[i]);
         }
-        const float r = ((sqrtf((float)best) + rho) * 1.00001f + 3.0f * eps) * inv_m + 1e-3f;
-        if (!(r < (float)IW_RMAX)) {   // also NaN
-            mark(flag);
-            continue;
+        // float64 among the candidates within the margin of the smallest (usually one: then its fp32 distance decides)
+        const float lim = d1 * 1.000002f + 1e-30f;
+        double best = 1e300;
+        long arg = 0;
+        int nclose = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) nclose += dist[i] <= lim ? 1 : 0;
+        if (nclose == 1) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (dist[i] <= lim) arg = corner_index(i);
+            best = (double)d1;
+        } else {   // (NaN distances: nclose == 0, best stays huge and the radius test below marks the point)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (!(dist[i] <= lim)) continue;
+                const double dx = (double)pos[i][0] - gx, dy = (double)pos[i][1] - gy, dz = HASZ ? (double)pos[i][2] - gz : 0.0;
+                const double d = dx * dx + dy * dy + dz * dz;
+                const long idx = corner_index(i);
+                if (d < best || (d == best && idx < arg)) best = d, arg = idx;
+            }
         }
-        const int lox = max((int)ceilf(vc[0] - r), 0), hix = min((int)floorf(vc[0] + r), vol.X - 1);
-        const int loy = max((int)ceilf(vc[1] - r), 0), hiy = min((int)floorf(vc[1] + r), vol.Y - 1);
-        if (!(lox >= c0x && hix <= c1x && loy >= c0y && hiy <= c1y)) {
-            best = 1e300, arg = 0;   // the whole box in float64 (r >= 1 here: it contains the cell)
-            for (int x = lox; x <= hix; ++x)
-                for (int yy = loy; yy <= hiy; ++yy) candidate(x, yy);
+        // R bounds |a|, a = s(v*) - s(v) for the nearest voxel v*: by the triangle inequality d0 + rho; and (round 3) by the
+        // angle between a and c = g - s(v):  |a - c| <= d0  gives  |a|^2 <= d0^2 - rho^2 + 2 a.c,  and with a = (M + E)(v* - v),
+        // |E|_F <= drift_s, |v* - v| <= |a| / m:  a.c <= |a| sigma,  sigma = (|w+| + drift_s rho) / m,  where w = M^T c and
+        // w+ keeps of w what can have the sign of v* - v: all of a free axis, nothing of the outward half of an axis on which
+        // v sits on a face of the volume.  Hence |a| <= sigma + sqrt(sigma^2 + d0^2 - rho^2).  For a pre-image inside the
+        // volume this is d0 instead of d0 + rho (rho ~ 0); for a lattice point whose pre-image LEFT the volume (c points
+        // outwards, rho = how far, d0 barely larger: the nearest voxel sits next to v on the face) it is ~1/2 voxel where the
+        // triangle inequality gives 2 rho -- boxes of (4 rho + 1)^2 voxels along every edge the warp moves inwards.
+        const float d0f = sqrtf((float)best);
+        int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        bool inside = true, far = false;
+        auto window = [&](float R) {   // the radii for |a| <= R, the voxels within them, whether those are the cell's
+            const float r = R * inv_m + 1e-3f;
+            far = !(r < (float)IW_RMAX);   // also NaN: for the exhaustive kernel
+            float rad[3] = {r, r, r};
+            if (HASZ) {   // the anisotropic radii (iwarp_min_stretch); never larger than the isotropic one
+                const float Rp = R * an_df, md = an_mu * fabsf(vc[2] - rintf(vc[2]));
+                const float inplane = sqrtf(fmaxf((Rp - md) * (Rp + md), 0.0f)) * 1.00001f;
+                const float rz = Rp * an_imu * 1.00001f;
+                const float rxy = (inplane + an_t * rz) * an_im2 * 1.00001f + 1e-3f;
+                rad[0] = rad[1] = fminf(r, rxy);   // (NaN or inf constants: fminf keeps r)
+                rad[2] = fminf(r, rz + 1e-3f);
+            }
+            inside = true;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                lo[d] = max((int)ceilf(vc[d] - rad[d]), 0), hi[d] = min((int)floorf(vc[d] + rad[d]), S[d] - 1);
+                inside = inside && lo[d] >= c0[d] && hi[d] <= c1[d];
+            }
+        };
+        const float R1 = (d0f + rho) * 1.00001f + 3.0f * eps;
+        window(R1);
+        if (far || !inside) {   // (few points: the sharper bound costs nothing where the first one already says "the cell")
+            float wp = 0.0f;
+#pragma unroll
+            for (int e = 0; e < ND; ++e) {
+                float w = 0.0f;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) w = fmaf(an[6 + 3 * d + e], res[d], w);
+                const bool lower = !(vc[e] > 0.0f), upper = !(vc[e] < (float)(S[e] - 1));
+                const float wv = lower ? (upper ? 0.0f : fmaxf(w, 0.0f)) : (upper ? fmaxf(-w, 0.0f) : fabsf(w));
+                wp = fmaf(wv, wv, wp);
+            }
+            const float drift_s = an[4], m_fro = an[5];
+            const float sigma = ((sqrtf(wp) + 2.0f * m_fro * eps) * 1.0001f + drift_s * (rho + eps)) * inv_m * 1.00001f;
+            const float D0 = d0f * 1.00001f + 2.0f * eps, rlo = fmaxf(rho * 0.99999f - eps, 0.0f);
+            const float R2 = (sigma + sqrtf(fmaf(sigma, sigma, fmaxf((D0 - rlo) * (D0 + rlo), 0.0f)))) * 1.00001f + eps;
+            if (R2 < R1) window(R2);   // (NaN: the first window stays)
         }
-        out[(long)b * ldo + g] = y[arg];
-        *flag = 0;
+        if (far && valid) mark(flag);
+#ifdef DNMF_IW_NOBOX   // timing study only (wrong results): what the kernel costs without the box
+        inside = true;
+#endif
+        const bool box = valid && !far && !inside;
+#ifdef DNMF_IW_COUNTBOX   // study only: the count of the call = points that searched a box
+        if (box) atomicAdd(&marked[b], 1u);
+#endif
+        // The box (a radius >= 1: it contains the cell).  Boxes are rare -- lattice points whose pre-image left the volume,
+        // a strip of them along an edge under a shift -- and large there (rho of a few voxels: 100-250 candidates), and one
+        // lane walking such a box alone holds its wave for ten times the wave's own work: at 512x512x2 under shifts of one
+        // voxel 0.3 % of the points doubled the kernel's time.  So the WAVE searches the box of each of its lanes in turn,
+        // candidate c of the box by lane c mod 64, in float64 on the fp32 positions (the reference's comparison), the
+        // result a lexicographic minimum of (distance, voxel index) over the lanes.  When more than IW_SHARE lanes of a wave
+        // need a box (strong warps everywhere) each lane walks its own, ranked in fp32 first.
+        unsigned long long need = __ballot(box);
+        if (__builtin_popcountll(need) <= IW_SHARE) {
+            while (need) {
+                const int src = __builtin_ctzll(need);
+                need &= need - 1;
+                const int l0 = __builtin_amdgcn_readlane(lo[0], src), l1 = __builtin_amdgcn_readlane(lo[1], src),
+                          l2 = __builtin_amdgcn_readlane(lo[2], src);
+                const int n1 = __builtin_amdgcn_readlane(hi[1], src) - l1 + 1, n2 = __builtin_amdgcn_readlane(hi[2], src) - l2 + 1;
+                const int n = (__builtin_amdgcn_readlane(hi[0], src) - l0 + 1) * n1 * n2;
+                const int sy = __builtin_amdgcn_readlane(gy, src), sz = __builtin_amdgcn_readlane(gz, src);
+                double cb = 1e300;
+                long ca = 0;
+                for (int c = lane; c < n; c += 64) {
+                    const int t = HASZ ? c / n2 : c, zz = HASZ ? l2 + (c - t * n2) : 0;
+                    const int xo = t / n1, x = l0 + xo, yy = l1 + (t - xo * n1);
+                    float px, py, pz;
+                    iwarp_position_t<HASZ, FAST>(bt, vol, x, yy, zz, px, py, pz);
+                    const double ex = (double)px - gx, ey = (double)py - sy, ez = HASZ ? (double)pz - sz : 0.0;
+                    const double dd = ex * ex + ey * ey + ez * ez;
+                    const long idx = ((long)x * vol.Y + yy) * vol.Z + zz;
+                    if (dd < cb || (dd == cb && idx < ca)) cb = dd, ca = idx;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const double od = __shfl_xor(cb, off);
+                    const long oa = __shfl_xor(ca, off);
+                    if (od < cb || (od == cb && oa < ca)) cb = od, ca = oa;
+                }
+                if (lane == src) best = cb, arg = ca;
+            }
+        } else if (box) {
+            // voxels beyond the cell are ranked in fp32 against the cell's result; a voxel takes part in the float64
+            // comparison only when its fp32 distance is within the margin of the best so far
+            float bestf = (float)best;
+            for (int x = lo[0]; x <= hi[0]; ++x)
+                for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                    for (int zz = lo[2]; zz <= hi[2]; ++zz) {
+                        if (x >= c0[0] && x <= c1[0] && yy >= c0[1] && yy <= c1[1] && zz >= c0[2] && zz <= c1[2]) continue;   // a corner
+                        float sx, sy, sz;
+                        iwarp_position_t<HASZ, FAST>(bt, vol, x, yy, zz, sx, sy, sz);
+                        const float dx = sx - gf[0], dy = sy - gf[1], dz = HASZ ? sz - gf[2] : 0.0f;
+                        const float d = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                        if (!(d <= bestf * 1.000002f + 1e-30f)) continue;
+                        const double ex = (double)sx - gx, ey = (double)sy - gy, ez = HASZ ? (double)sz - gz : 0.0;
+                        const double dd = ex * ex + ey * ey + ez * ez;
+                        const long idx = ((long)x * vol.Y + yy) * vol.Z + zz;
+                        if (dd < best || (dd == best && idx < arg)) best = dd, arg = idx, bestf = fminf(bestf, d);
+                    }
+        }
+        if (valid && !far) {
+            out[(long)b * ldo + g] = y[arg];
+            *flag = 0;
+        }
     }
 }
 
@@ -429,12 +628,12 @@ __global__ void sum_marked_kernel(const unsigned *__restrict__ marked, int B, un
     if (b < B && marked[b]) atomicAdd(count, (unsigned long long)marked[b]);
 }
 
-// one flag byte per lattice point and frame, then one float and one counter per frame
+// one flag byte per lattice point and frame, then IW_NK floats and one counter per frame
 static size_t iwarp_flag_bytes(int X, int Y, int Z, int B) { return ((size_t)X * Y * Z * B + 7) / 8 * 8; }
 
 size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B) {
     if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
-    return iwarp_flag_bytes(X, Y, Z, B) + (sizeof(float) + sizeof(unsigned)) * (size_t)B + sizeof(unsigned);
+    return iwarp_flag_bytes(X, Y, Z, B) + (dnmf::IW_NK * sizeof(float) + sizeof(unsigned)) * (size_t)B + sizeof(unsigned);
 }
 
 int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X, int Y, int Z, const float *beta, int T,
@@ -452,7 +651,7 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
     unsigned char *todo = static_cast<unsigned char *>(workspace);
     const dim3 grid((unsigned)((vol.P + 255) / 256), (unsigned)B);
     float *stretch = reinterpret_cast<float *>(todo + iwarp_flag_bytes(X, Y, Z, B));
-    unsigned *marked = reinterpret_cast<unsigned *>(stretch + B);
+    unsigned *marked = reinterpret_cast<unsigned *>(stretch + IW_NK * (size_t)B);   // IW_NK constants per frame
     if (exhaustive) {
         marked = nullptr;
         hipError_t e = hipMemsetAsync(todo, 1, (size_t)vol.P * B, st);
@@ -467,19 +666,24 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
             sc.k[d] = pinned ? 1.0f : (float)(S[d] - 1) / (float)S[d];
             sc.hk[d] = pinned ? 0.5f : 0.5f * (float)S[d] / (float)(S[d] - 1);   // an axis of one voxel: inf, and every point of
         }                                                                       // the volume goes to the exhaustive search
-        if (Z > 1)
-            hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
-                               times, stretch, sc, out, ldo, todo, marked);
-        else {
-            const int nyb = (Y + 255) / 256;
-            const dim3 rgrid((unsigned)(nyb * ((X + IW_ROWS - 1) / IW_ROWS)), (unsigned)B);
-            if (vol.fastdiv)
-                hipLaunchKernelGGL(image_iwarp_rows_kernel<1>, rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,
-                                   stretch, sc, out, ldo, todo, marked, nyb);
+        const int nyb = (Y * Z + 255) / 256;
+        const dim3 rgrid((unsigned)(nyb * ((X + IW_ROWS - 1) / IW_ROWS)), (unsigned)B);
+#define DNMF_IW_ROWS_LAUNCH(HZ, FD)                                                                                              \
+    hipLaunchKernelGGL((image_iwarp_rows_kernel<HZ, FD>), rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,  \
+                       stretch, sc, out, ldo, todo, marked, nyb)
+        if (X == 1 || Y == 1) {   // an axis of one voxel (its hk is infinite): the one-point-per-thread kernel marks every point
+            if (Z > 1)
+                hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
+                                   times, stretch, sc, out, ldo, todo, marked);
             else
-                hipLaunchKernelGGL(image_iwarp_rows_kernel<0>, rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,
-                                   stretch, sc, out, ldo, todo, marked, nyb);
+                hipLaunchKernelGGL(image_iwarp_window_kernel<false>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
+                                   times, stretch, sc, out, ldo, todo, marked);
+        } else if (Z > 1) {
+            if (vol.fastdiv) DNMF_IW_ROWS_LAUNCH(true, 1); else DNMF_IW_ROWS_LAUNCH(true, 0);
+        } else {
+            if (vol.fastdiv) DNMF_IW_ROWS_LAUNCH(false, 1); else DNMF_IW_ROWS_LAUNCH(false, 0);
         }
+#undef DNMF_IW_ROWS_LAUNCH
     }
     if (fallback_count && marked) {
         hipLaunchKernelGGL(sum_marked_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, marked, B, fallback_count);

@@ -206,7 +206,7 @@ def test_G6_pushforward_surface(M, O):
             assert d[1] - d[0] < 1e-6, (t, q, d[:3])
 
 
-@pytest.mark.parametrize("sz", [[12, 10, 2], [64, 48, 1], [40, 36, 3], [160, 128, 1]])
+@pytest.mark.parametrize("sz", [[12, 10, 2], [64, 48, 1], [40, 36, 3], [160, 128, 1], [96, 64, 2], [48, 40, 5]])
 def test_registered_video_window_search_equals_exhaustive(M, O, sz):
     """K7's window search must return exactly what the exhaustive search (every voxel a candidate for every lattice
     point, the kernel of round 1) returns: identity (every lattice point of an odd slice is a tie at Z = 2), the
