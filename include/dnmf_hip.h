@@ -280,8 +280,8 @@ int dnmf_comm_destroy(dnmf_comm_t comm);
  * a window around the back-mapped lattice point whose radius follows from a lower bound of the warp's stretch, so
  * it returns what an exhaustive search returns; lattice points whose window would be too large (a folding or
  * violent warp, points far outside the warped image) are searched exhaustively.
- *   out (B,P) row stride ldo;  workspace: dnmf_image_iwarp_workspace(X,Y,Z,B) bytes (one flag per lattice point, one stretch bound and one
- *   counter of marked points per frame), 8-byte aligned;
+ *   out (B,P) row stride ldo;  workspace: dnmf_image_iwarp_workspace(X,Y,Z,B) bytes (one flag per lattice point, sixteen constants of the
+ *   frame's warp and one counter of marked points per frame), 8-byte aligned;
  *   exhaustive != 0: every lattice point by the exhaustive search (the checker of the window search);
  *   fallback_count: NULL, or one uint64 INCREMENTED by the lattice points that took the exhaustive search. */
 size_t dnmf_image_iwarp_workspace(int X, int Y, int Z, int B);
