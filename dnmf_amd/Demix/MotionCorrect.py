@@ -11,9 +11,15 @@ to what ``apply_shifts_points`` (``:351-371``) needs: the per-patch shifts of th
 ``tile_and_correct_wrapper`` ``:2029-2037`` hard-codes it).  The registration runs on the GPU (K8 ``dnmf_register_patches``:
 matrix-multiply DFTs, no FFT library; ``csrc/register_patches.hip``).
 
-Not offered (``NotImplementedError``): rigid-only correction of the frames, the corrected movie, 2-D (cv2) registration,
-``shifts_opencv=False`` (cubic resize of the shift field), memory-mapped files, ``dview``.  ``template=None`` takes the
-temporal median of the video instead of the reference's rigid pre-pass (``:298-301``).
+``template=None`` runs the reference's rigid pre-pass first (``motion_correct_rigid`` ``:213-258`` ->
+``motion_correct_batch_rigid`` ``:1770-1877``): the binned median of the video as the first template, every frame
+registered to it and moved by its shift through the phases of its spectrum (``apply_shifts_dft``), the NaN-aware mean of the
+moved frames as the template of the piecewise pass -- K8 ``dnmf_rigid_correct``.  ``motion_correct_rigid`` is also offered
+on its own (``shifts_rig``, ``total_template_rig``, ``templates_rig``; the corrected movie in ``mc`` only with
+``save_corrected=True``: it is as large as the video).
+
+Not offered (``NotImplementedError``): the piecewise-corrected movie, 2-D (cv2) registration, ``shifts_opencv=False`` (cubic
+resize of the shift field), ``border_nan`` 'min' / 'copy', memory-mapped files, ``dview``, ``gSig_filt``.
 
 Parity: the reference module cannot be imported in the build container (cv2, skimage and ``past`` are absent, ``np.int``
 is gone from numpy 2) and ships no fixture; this class is checked against ``oracle/motion_oracle.py``, a numpy restatement
@@ -34,7 +40,7 @@ class MotionCorrect(object):
                  num_splits_to_process_rig=None, strides=(96, 96, 1), overlaps=(32, 32, 1), splits_els=1,
                  num_splits_to_process_els=None, upsample_factor_grid=4, max_deviation_rigid=3, shifts_opencv=True,
                  nonneg_movie=True, gSig_filt=None, use_cuda=False, border_nan=True, pw_rigid=False, num_frames_split=80,
-                 var_name_hdf5='mov', is3D=True, indices=(slice(None), slice(None))):
+                 var_name_hdf5='mov', is3D=True, indices=(slice(None), slice(None)), save_corrected=False):
         ops._lib.load()   # fail here, loudly, if the HIP library is not built
         if not is3D:
             raise NotImplementedError("MotionCorrect: only the 3-D functions are built (apply_shifts_points is 3-D)")
@@ -55,7 +61,14 @@ class MotionCorrect(object):
         self.shifts_opencv = True
         self.min_mov = min_mov
         self.nonneg_movie = nonneg_movie
+        if border_nan not in (True, False):
+            raise NotImplementedError("MotionCorrect: border_nan 'min' / 'copy' are not built")
         self.border_nan = border_nan
+        self.niter_rig = int(niter_rig)
+        if splits_rig != 1 or splits_els != 1 or num_splits_to_process_rig is not None or num_splits_to_process_els is not None:
+            raise NotImplementedError("MotionCorrect: splits (chunks for a process pool) are not built; the GPU walks the video "
+                                      "in pieces of its own")
+        self.save_corrected = bool(save_corrected)
         self.pw_rigid = bool(pw_rigid)
         self.is3D = True
         self.upsample_factor_fft = 10     # tile_and_correct_wrapper :2029-2037
@@ -70,28 +83,86 @@ class MotionCorrect(object):
         return v.to(device, torch.float32).reshape(v.shape[0], -1).contiguous(), sz
 
     def motion_correct(self, template=None):
-        """Reference :175-211; only the piecewise-rigid shifts are built."""
-        if not self.pw_rigid:
-            raise NotImplementedError("MotionCorrect.motion_correct: rigid correction of the frames is not built; "
-                                      "set pw_rigid=True (the shifts apply_shifts_points needs)")
-        self.motion_correct_pwrigid(template=template)
-        b0 = np.ceil(np.max([np.max(np.abs(self.x_shifts_els)), np.max(np.abs(self.y_shifts_els)),
-                             np.max(np.abs(self.z_shifts_els))]))
+        """Reference :176-211."""
+        if self.min_mov is None:
+            self.min_mov = min(float(torch.as_tensor(v).min()) for v in self.video)     # (:193-195: of the first video)
+        if self.pw_rigid:
+            self.motion_correct_pwrigid(template=template)
+            b0 = np.ceil(np.max([np.max(np.abs(self.x_shifts_els)), np.max(np.abs(self.y_shifts_els)),
+                                 np.max(np.abs(self.z_shifts_els))]))
+        else:
+            self.motion_correct_rigid(template=template)
+            b0 = np.ceil(np.max(np.abs(self.shifts_rig)))
         self.border_to_0 = int(b0)
         return self
+
+    @staticmethod
+    def _bin_median_3d(frames, window=10):
+        """bin_median_3d :464-494 on (T, P) rows: mean over groups of frames (group j = frames j, j + num_windows, ...: the
+        reference's reshape), NaN-aware median over the groups (mean of the two middle values for an even count)."""
+        T = frames.shape[0]
+        window = min(window, T)
+        nw = T // window
+        bins = frames[:nw * window].view(window, nw, -1).nanmean(0)          # (nw, P)
+        srt = bins.sort(0).values                                            # NaNs last
+        cnt = (~torch.isnan(bins)).sum(0).clamp(min=1)
+        lo = srt.gather(0, ((cnt - 1) // 2)[None])[0]
+        hi = srt.gather(0, (cnt // 2)[None])[0]
+        return 0.5 * (lo + hi)
+
+    def motion_correct_rigid(self, template=None):
+        """Reference :213-258 -> motion_correct_batch_rigid :1770-1877 (3-D, one chunk): fills ``total_template_rig``,
+        ``templates_rig``, ``shifts_rig`` (one (x, y, z) tuple per frame, the registration's shift with its sign flipped,
+        :1574) and -- only with ``save_corrected=True`` -- ``mc`` (one (X, Y, Z, T) array per video)."""
+        self.total_template_rig = template
+        self.templates_rig, self.shifts_rig, self.mc = [], [], []
+        for video_cur in self.video:
+            frames, sz = self._frames(video_cur)
+            if self.min_mov is None:
+                self.min_mov = float(frames.min())
+            if self.total_template_rig is None:
+                tmpl = self._bin_median_3d(frames)                           # :1826
+            else:
+                tmpl = torch.as_tensor(np.asarray(self.total_template_rig) if not torch.is_tensor(self.total_template_rig)
+                                       else self.total_template_rig).to(device, torch.float32).reshape(-1)
+            add = float(np.float32(-self.min_mov))                           # (:2122: passed on as a float32)
+            step = max(1, min(frames.shape[0], (1 << 30) // (4 * frames.shape[1]))) if self.save_corrected else frames.shape[0]
+            rigid = None
+            for it in range(max(1, self.niter_rig)):
+                last = it == max(1, self.niter_rig) - 1
+                tsum = tcount = None
+                parts, moved = [], []
+                for f0 in range(0, frames.shape[0], step):
+                    r, out, tsum, tcount = ops.rigid_correct(frames[f0:f0 + step], tmpl, sz, self.max_shifts, self.upsample_factor_fft,
+                                                             add_to_movie=add, border_nan=bool(self.border_nan),
+                                                             want_frames=self.save_corrected and last, tsum=tsum, tcount=tcount)
+                    parts.append(r)
+                    if out is not None:
+                        moved.append(out.cpu())
+                rigid = torch.cat(parts)
+                new_temp = tsum / tcount                                     # nanmean :2057 (0 / 0: NaN)
+                new_temp = torch.where(torch.isnan(new_temp), new_temp[~torch.isnan(new_temp)].min(), new_temp)   # :2058
+                tmpl = new_temp
+            if template is None:
+                self.total_template_rig = tmpl.view(*sz).cpu().numpy()
+            self.templates_rig.append(tmpl.view(*sz).cpu().numpy())
+            self.shifts_rig += [tuple(float(-v) for v in row) for row in rigid.cpu().numpy()]
+            if moved:
+                self.mc.append(torch.cat(moved).view(-1, *sz).permute(1, 2, 3, 0).numpy())
 
     def motion_correct_pwrigid(self, template=None, show_template=False):
         """Reference :260-328: fills ``x_shifts_els``, ``y_shifts_els``, ``z_shifts_els`` (one (NP,) array per frame),
         ``shifts_rig`` (the rigid shift of every frame), ``coord_shifts_els`` (the patch grid indices) and
         ``total_template_els``."""
         self.x_shifts_els, self.y_shifts_els, self.z_shifts_els = [], [], []
-        self.coord_shifts_els, self.shifts_rig = [], []
+        self.coord_shifts_els = []
         for video_cur in self.video:
             frames, sz = self._frames(video_cur)
             if self.min_mov is None:
                 self.min_mov = float(frames.min())           # :196-199
             if template is None:
-                tmpl = frames.median(0).values               # (the reference: a rigid pre-pass, :298-301)
+                self.motion_correct_rigid()                  # :298-301 (every video of the list, as the reference does)
+                tmpl = torch.from_numpy(np.ascontiguousarray(self.total_template_rig)).to(device, torch.float32).reshape(-1)
             else:
                 tmpl = torch.as_tensor(np.asarray(template) if not torch.is_tensor(template) else template).to(
                     device, torch.float32).reshape(-1)
@@ -107,7 +178,6 @@ class MotionCorrect(object):
                 self.y_shifts_els.append(p[t, :, 1].copy())
                 self.z_shifts_els.append(p[t, :, 2].copy())
                 self.coord_shifts_els.append(grid)
-            self.shifts_rig += [tuple(r) for r in rigid.cpu().numpy()]
             self._patch_shifts = patch                       # (T, NP, 3) on the GPU, for apply_shifts_points
 
     def _centers(self, sz):

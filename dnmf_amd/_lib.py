@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DNMF_LIB selects another build of the library (kernel-variant timing, ablations); the product default is in-tree
 LIB_PATH = os.environ.get("DNMF_LIB") or os.path.join(_HERE, "libdnmf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dnmf_register_patches_grid": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dnmf_register_patches_workspace": (_sz, [_i, _i, _i, _vp, _vp, _i]),
     "dnmf_register_patches": (_i, [_vp, _l, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "dnmf_rigid_correct_workspace": (_sz, [_i, _i, _i, _i]),
+    "dnmf_rigid_correct": (_i, [_vp, _l, _vp, _i, _vp, _i, _i, _i, _vp, _i, C.c_float, _i, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
     "dnmf_apply_shifts_points": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "dnmf_comm_unique_id": (_i, [_vp]),
     "dnmf_comm_init": (_i, [_vp, _vp, _i, _i]),

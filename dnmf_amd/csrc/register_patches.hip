@@ -300,6 +300,105 @@ static void mc_launch_axis(McAxis a, int items, size_t maxD_bytes, hipStream_t s
     hipLaunchKernelGGL(mc_axis_kernel, grid, dim3(256), (size_t)a.n * a.uf * sizeof(float2), st, a);
 }
 
+// numerators of the positions r + s_d of a frame's shifted grid: pos[(item 3 + d) nmax + r] = r uf + round(s_d uf)
+__global__ void mc_shift_pos_kernel(const float *shifts, int uf, McBoxes bx, int nmax, int *pos) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, item = blockIdx.y;
+    if (e >= 3 * nmax) return;
+    const int d = e / nmax, r = e - d * nmax;
+    const int sn = (int)lrintf(shifts[(long)item * 3 + d] * (float)uf);
+    pos[((long)item * 3 + d) * nmax + r] = r < bx.n[d] ? r * uf + sn : INT_MIN;
+}
+
+// apply_shifts_dft :1098-1119 and tile_and_correct_3d :1573: real part of the shifted frames minus add_to_movie, NaN where the
+// shift brought in voxels from the other side -- with the reference's pairing: the border of axis 0 follows the shift
+// of axis 1 and the other way round (:1083 swaps the first two shifts for the frequencies, :1104-1113 use the swapped pair on
+// the axes in order).  Written to `corrected` and / or added into the per-voxel sums and counts of the finite values (the
+// nanmean of tile_and_correct_wrapper :2057).  The factor exp(i diffphase) of :1097 is left out: diffphase is the argument of
+// the correlation's peak value, zero up to rounding for real images (1e-8 here), and it multiplies a real image.
+__global__ __launch_bounds__(256) void mc_shifted_frames_kernel(const float2 *img, int nf, int X, int Y, int Z, const float *shifts,
+                                                                float add, int border_nan, float *corrected, long ldc,
+                                                                float *tsum, int *tcount) {
+    const long P = (long)X * Y * Z;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const int z = (int)(g % Z), y = (int)((g / Z) % Y), x = (int)(g / ((long)Y * Z));
+    float acc = 0.0f;
+    int cnt = 0;
+    for (int f = 0; f < nf; ++f) {
+        float v = img[(long)f * P + g].x - add;
+        if (border_nan) {
+            const float s0 = shifts[3 * f], s1 = shifts[3 * f + 1], s2 = shifts[3 * f + 2];
+            const int max_h = (int)ceilf(fmaxf(0.0f, s1)), min_h = (int)floorf(fminf(0.0f, s1));
+            const int max_w = (int)ceilf(fmaxf(0.0f, s0)), min_w = (int)floorf(fminf(0.0f, s0));
+            const int max_d = (int)ceilf(fmaxf(0.0f, s2)), min_d = (int)floorf(fminf(0.0f, s2));
+            // python: a[:max_h] and, for min_h < 0, a[min_h:] (slices clip to the axis)
+            const bool out = x < max_h || (min_h < 0 && x >= max(X + min_h, 0)) || y < max_w || (min_w < 0 && y >= max(Y + min_w, 0)) ||
+                             z < max_d || (min_d < 0 && z >= max(Z + min_d, 0));
+            if (out) v = __builtin_nanf("");
+        }
+        if (corrected) corrected[(long)f * ldc + g] = v;
+        if (v == v) acc += v, ++cnt;
+    }
+    if (tsum) tsum[g] += acc, tcount[g] += cnt;
+}
+
+// The transforms of one call: buffers carved from its workspace, and the passes built from mc_axis_kernel.
+struct McRun {
+    hipStream_t st;
+    int X, Y, Z, uf, region, max_dev;
+    float add;
+    float2 *bufA, *bufB, *inv1, *inv2, *cc;
+    int *win, *pos_up, *peak, *iota, *mshift;
+
+    // forward DFT of `nitems` boxes of frames [first, ...) (or of the template when ld == 0): voxels -> spectrum in A
+    void forward(const McBoxes &bx, const float *src, long ld, const int *ids, int first, int nitems, float2 *A, float2 *Bf) const {
+        McAxis a{};
+        a.bx = bx, a.X = X, a.Y = Y, a.Z = Z, a.add = add, a.first_frame = first;
+        a.uf = 1, a.sign = -1, a.scale = 1.0f, a.pos = iota, a.pos_item_stride = 0, a.pos_off = 0;
+        // z: voxels -> A
+        a.mode = 0, a.frames = src, a.ldf = ld, a.frame_ids = ids;
+        a.outer = bx.n[0] * bx.n[1], a.n = bx.n[2], a.inner = 1, a.m = bx.n[2], a.out = A;
+        mc_launch_axis(a, nitems, 0, st);
+        // y: A -> B
+        a.mode = 1, a.in = A, a.outer = bx.n[0], a.n = bx.n[1], a.inner = bx.n[2], a.m = bx.n[1], a.out = Bf;
+        mc_launch_axis(a, nitems, 0, st);
+        // x: B -> A
+        a.in = Bf, a.outer = 1, a.n = bx.n[0], a.inner = bx.n[1] * bx.n[2], a.m = bx.n[0], a.out = A;
+        mc_launch_axis(a, nitems, 0, st);
+    }
+    // P = spec conj(tspec) onto mm positions per axis (numerators in posbuf (items or 1, 3, MC_MW), over ufac) -> cc (items, mm^3)
+    void inverse(const McBoxes &bx, const float2 *spec, const float2 *tspec, const int *posbuf, int pstride, int mm, int ufac,
+                 int nitems) const {
+        McAxis a{};
+        a.bx = bx, a.uf = ufac, a.sign = 1, a.pos = posbuf, a.pos_item_stride = pstride, a.m = mm;
+        // x (with the product): (1, n0, n1 n2) -> (1, mm, n1 n2)
+        a.mode = 2, a.in = spec, a.other = tspec, a.outer = 1, a.n = bx.n[0], a.inner = bx.n[1] * bx.n[2], a.pos_off = 0;
+        a.scale = 1.0f / (float)bx.n[0], a.out = inv1;
+        mc_launch_axis(a, nitems, 0, st);
+        // y: (mm, n1, n2) -> (mm, mm, n2)
+        a.mode = 1, a.in = inv1, a.outer = mm, a.n = bx.n[1], a.inner = bx.n[2], a.pos_off = MC_MW;
+        a.scale = 1.0f / (float)bx.n[1], a.out = inv2;
+        mc_launch_axis(a, nitems, 0, st);
+        // z: (mm mm, n2, 1) -> (mm mm, mm, 1)
+        a.in = inv2, a.outer = mm * mm, a.n = bx.n[2], a.inner = 1, a.pos_off = 2 * MC_MW;
+        a.scale = 1.0f / (float)bx.n[2], a.out = cc;
+        mc_launch_axis(a, nitems, 0, st);
+    }
+    // one registration pass over `nitems` boxes: window -> peak -> upsampled -> shifts
+    void registration(const McBoxes &bx, const float2 *spec, const float2 *tspec, const float *rigid, int first, int nitems,
+                      float *shifts_out, float3 sgn) const {
+        const int witems = rigid ? nitems : 1;
+        hipLaunchKernelGGL(mc_window_kernel, dim3((unsigned)((witems * 3 + 63) / 64)), dim3(64), 0, st, win, witems, bx.nbox,
+                           rigid ? rigid + (long)first * 3 : nullptr, max_dev, mshift, bx);
+        inverse(bx, spec, tspec, win, rigid ? 3 * MC_MW : 0, MC_MW, 1, nitems);
+        hipLaunchKernelGGL((mc_peak_kernel<0>), dim3((unsigned)nitems), dim3(256), 0, st, cc, MC_MW, win, rigid ? 3 * MC_MW : 0, peak,
+                           pos_up, uf, region, bx, (float *)nullptr, sgn);
+        inverse(bx, spec, tspec, pos_up, 3 * MC_MW, region, uf, nitems);
+        hipLaunchKernelGGL((mc_peak_kernel<1>), dim3((unsigned)nitems), dim3(256), 0, st, cc, region, win, 0, peak, pos_up, uf, region,
+                           bx, shifts_out, sgn);
+    }
+};
+
 }  // namespace dnmf
 
 extern "C" {
@@ -372,12 +471,11 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
     DNMF_REQUIRE(NP > 0 && NP <= 65535, DNMF_E_SHAPE, "dnmf_register_patches: strides + overlaps must fit the volume (%d patches)", NP);
     DNMF_REQUIRE(upsample_factor >= 1 && (int)((upsample_factor * 3 + 1) / 2) <= MC_MW, DNMF_E_UNSUPPORTED,
                  "dnmf_register_patches: upsample_factor %d (ceil(1.5 factor) <= %d)", upsample_factor, MC_MW);
-    const int uf = upsample_factor, region = (upsample_factor * 3 + 1) / 2;   // ceil(1.5 uf)
     const int S[3] = {X, Y, Z};
     const int w[3] = {strides[0] + overlaps[0], strides[1] + overlaps[1], strides[2] + overlaps[2]};
     for (int d = 0; d < 3; ++d) {
-        DNMF_REQUIRE(S[d] * uf <= MC_MAXD, DNMF_E_UNSUPPORTED, "dnmf_register_patches: axis %d of %d voxels x upsample factor %d > %d",
-                     d, S[d], uf, MC_MAXD);
+        DNMF_REQUIRE(S[d] * upsample_factor <= MC_MAXD, DNMF_E_UNSUPPORTED,
+                     "dnmf_register_patches: axis %d of %d voxels x upsample factor %d > %d", d, S[d], upsample_factor, MC_MAXD);
         DNMF_REQUIRE(max_shifts[d] >= 0 && (S[d] <= MC_MW || 2 * max_shifts[d] <= MC_MW) && max_deviation_rigid >= 1 &&
                          (w[d] <= MC_MW || 2 * max_deviation_rigid + 1 <= MC_MW),
                      DNMF_E_UNSUPPORTED, "dnmf_register_patches: search window of axis %d wider than %d shifts", d, MC_MW);
@@ -385,7 +483,9 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
     DNMF_REQUIRE(workspace_bytes >= dnmf_register_patches_workspace(X, Y, Z, strides, overlaps, B), DNMF_E_WORKSPACE,
                  "dnmf_register_patches: workspace %zu < %zu bytes", workspace_bytes,
                  dnmf_register_patches_workspace(X, Y, Z, strides, overlaps, B));
-    hipStream_t st = (hipStream_t)stream;
+    McRun r{};
+    r.st = (hipStream_t)stream, r.X = X, r.Y = Y, r.Z = Z, r.add = add_to_movie, r.uf = upsample_factor;
+    r.region = (upsample_factor * 3 + 1) / 2, r.max_dev = max_deviation_rigid;   // ceil(1.5 uf)
     const long P = (long)X * Y * Z;
     const long pvox = (long)NP * w[0] * w[1] * w[2];
     const long per_frame = P > pvox ? P : pvox;
@@ -395,19 +495,19 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
     // carve the workspace
     char *at = static_cast<char *>(workspace);
     auto take = [&](size_t bytes) { char *p = at; at += mc_round(bytes); return p; };
-    float2 *bufA = reinterpret_cast<float2 *>(take((size_t)Bc * per_frame * sizeof(float2)));
-    float2 *bufB = reinterpret_cast<float2 *>(take((size_t)Bc * per_frame * sizeof(float2)));
+    r.bufA = reinterpret_cast<float2 *>(take((size_t)Bc * per_frame * sizeof(float2)));
+    r.bufB = reinterpret_cast<float2 *>(take((size_t)Bc * per_frame * sizeof(float2)));
     float2 *tF_full = reinterpret_cast<float2 *>(take((size_t)P * sizeof(float2)));
     float2 *tF_patch = reinterpret_cast<float2 *>(take((size_t)pvox * sizeof(float2)));
-    float2 *inv1 = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * biggest_n12 * sizeof(float2)));
-    float2 *inv2 = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * biggest_n12 * sizeof(float2)));
-    float2 *cc = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * MC_MW * MC_MW * sizeof(float2)));
-    int *win = reinterpret_cast<int *>(take((size_t)items_max * 3 * MC_MW * sizeof(int)));
-    int *pos_up = reinterpret_cast<int *>(take((size_t)items_max * 3 * MC_MW * sizeof(int)));
-    int *peak = reinterpret_cast<int *>(take((size_t)items_max * 3 * sizeof(int)));
-    int *iota = reinterpret_cast<int *>(take((size_t)16384 * sizeof(int)));
+    r.inv1 = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * biggest_n12 * sizeof(float2)));
+    r.inv2 = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * biggest_n12 * sizeof(float2)));
+    r.cc = reinterpret_cast<float2 *>(take((size_t)items_max * MC_MW * MC_MW * MC_MW * sizeof(float2)));
+    r.win = reinterpret_cast<int *>(take((size_t)items_max * 3 * MC_MW * sizeof(int)));
+    r.pos_up = reinterpret_cast<int *>(take((size_t)items_max * 3 * MC_MW * sizeof(int)));
+    r.peak = reinterpret_cast<int *>(take((size_t)items_max * 3 * sizeof(int)));
+    r.iota = reinterpret_cast<int *>(take((size_t)16384 * sizeof(int)));
     int *starts = reinterpret_cast<int *>(take((size_t)(NP + 1) * 3 * sizeof(int)));
-    int *mshift = reinterpret_cast<int *>(take(64));
+    r.mshift = reinterpret_cast<int *>(take(64));
 
     // patch starts (the whole-volume box is entry NP), max_shifts, the forward DFT's positions: small host -> device copies
     {
@@ -415,81 +515,135 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
         DNMF_REQUIRE(h, DNMF_E_WORKSPACE, "dnmf_register_patches: out of host memory");
         dnmf_register_patches_grid(X, Y, Z, strides, overlaps, dims, h);
         h[3 * NP] = h[3 * NP + 1] = h[3 * NP + 2] = 0;
-        hipError_t e = hipMemcpyAsync(starts, h, (size_t)(NP + 1) * 3 * sizeof(int), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(mshift, max_shifts, 3 * sizeof(int), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);   // h is freed below; the call is not on a hot path
+        hipError_t e = hipMemcpyAsync(starts, h, (size_t)(NP + 1) * 3 * sizeof(int), hipMemcpyHostToDevice, r.st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r.mshift, max_shifts, 3 * sizeof(int), hipMemcpyHostToDevice, r.st);
+        if (e == hipSuccess) e = hipStreamSynchronize(r.st);   // h is freed below; the call is not on a hot path
         free(h);
         DNMF_REQUIRE(e == hipSuccess, (int)e, "dnmf_register_patches: copy of the patch grid: %s", hipGetErrorString(e));
     }
     int nmax = X > Y ? X : Y;
     nmax = nmax > Z ? nmax : Z;
-    hipLaunchKernelGGL(mc_iota_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, st, iota, nmax);
+    hipLaunchKernelGGL(mc_iota_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, r.st, r.iota, nmax);
 
     McBoxes full;
     full.n[0] = X, full.n[1] = Y, full.n[2] = Z, full.nbox = 1, full.start = starts + 3 * NP;
     McBoxes pat;
     pat.n[0] = w[0], pat.n[1] = w[1], pat.n[2] = w[2], pat.nbox = NP, pat.start = starts;
 
-    // forward DFT of `items` boxes of frames [first, first + nf) (or of the template when src == tmpl): voxels -> spectrum in A
-    auto forward = [&](const McBoxes &bx, const float *src, long ld, const int *ids, int first, int nitems, float2 *A, float2 *Bf) {
-        McAxis a{};
-        a.bx = bx, a.X = X, a.Y = Y, a.Z = Z, a.add = add_to_movie, a.first_frame = first;
-        a.uf = 1, a.sign = -1, a.scale = 1.0f, a.pos = iota, a.pos_item_stride = 0, a.pos_off = 0;
-        // z: voxels -> A
-        a.mode = 0, a.frames = src, a.ldf = ld, a.frame_ids = ids;
-        a.outer = bx.n[0] * bx.n[1], a.n = bx.n[2], a.inner = 1, a.m = bx.n[2], a.out = A;
-        mc_launch_axis(a, nitems, 0, st);
-        // y: A -> B
-        a.mode = 1, a.in = A, a.outer = bx.n[0], a.n = bx.n[1], a.inner = bx.n[2], a.m = bx.n[1], a.out = Bf;
-        mc_launch_axis(a, nitems, 0, st);
-        // x: B -> A
-        a.in = Bf, a.outer = 1, a.n = bx.n[0], a.inner = bx.n[1] * bx.n[2], a.m = bx.n[0], a.out = A;
-        mc_launch_axis(a, nitems, 0, st);
-    };
-    // P = spec conj(tspec) onto mm positions per axis (numerators in posbuf (items or 1, 3, MC_MW), over ufac) -> cc (items, mm^3)
-    auto inverse = [&](const McBoxes &bx, const float2 *spec, const float2 *tspec, const int *posbuf, int pstride, int mm, int ufac,
-                       int nitems) {
-        McAxis a{};
-        a.bx = bx, a.uf = ufac, a.sign = 1, a.pos = posbuf, a.pos_item_stride = pstride, a.m = mm;
-        // x (with the product): (1, n0, n1 n2) -> (1, mm, n1 n2)
-        a.mode = 2, a.in = spec, a.other = tspec, a.outer = 1, a.n = bx.n[0], a.inner = bx.n[1] * bx.n[2], a.pos_off = 0;
-        a.scale = 1.0f / (float)bx.n[0], a.out = inv1;
-        mc_launch_axis(a, nitems, 0, st);
-        // y: (mm, n1, n2) -> (mm, mm, n2)
-        a.mode = 1, a.in = inv1, a.outer = mm, a.n = bx.n[1], a.inner = bx.n[2], a.pos_off = MC_MW;
-        a.scale = 1.0f / (float)bx.n[1], a.out = inv2;
-        mc_launch_axis(a, nitems, 0, st);
-        // z: (mm mm, n2, 1) -> (mm mm, mm, 1)
-        a.in = inv2, a.outer = mm * mm, a.n = bx.n[2], a.inner = 1, a.pos_off = 2 * MC_MW;
-        a.scale = 1.0f / (float)bx.n[2], a.out = cc;
-        mc_launch_axis(a, nitems, 0, st);
-    };
-    auto registration = [&](const McBoxes &bx, const float2 *spec, const float2 *tspec, const float *rigid, int first, int nitems,
-                            float *shifts_out, float3 sgn) {
-        const int witems = rigid ? nitems : 1;
-        hipLaunchKernelGGL(mc_window_kernel, dim3((unsigned)((witems * 3 + 63) / 64)), dim3(64), 0, st, win, witems, bx.nbox,
-                           rigid ? rigid + (long)first * 3 : nullptr, max_deviation_rigid, mshift, bx);
-        inverse(bx, spec, tspec, win, rigid ? 3 * MC_MW : 0, MC_MW, 1, nitems);
-        hipLaunchKernelGGL((mc_peak_kernel<0>), dim3((unsigned)nitems), dim3(256), 0, st, cc, MC_MW, win, rigid ? 3 * MC_MW : 0, peak,
-                           pos_up, uf, region, bx, (float *)nullptr, sgn);
-        inverse(bx, spec, tspec, pos_up, 3 * MC_MW, region, uf, nitems);
-        hipLaunchKernelGGL((mc_peak_kernel<1>), dim3((unsigned)nitems), dim3(256), 0, st, cc, region, win, 0, peak, pos_up, uf, region,
-                           bx, shifts_out, sgn);
-    };
-
     // template spectra (once)
-    forward(full, tmpl, 0, nullptr, 0, 1, tF_full, bufB);
-    forward(pat, tmpl, 0, nullptr, 0, NP, tF_patch, bufB);
+    r.forward(full, tmpl, 0, nullptr, 0, 1, tF_full, r.bufB);
+    r.forward(pat, tmpl, 0, nullptr, 0, NP, tF_patch, r.bufB);
     for (int f0 = 0; f0 < B; f0 += Bc) {
         const int nf = B - f0 < Bc ? B - f0 : Bc;
         // rigid shift of every frame of the chunk (:1559-1560), kept with its own sign
-        forward(full, frames, ldf, frame_ids, f0, nf, bufA, bufB);
-        registration(full, bufA, tF_full, nullptr, f0, nf, rigid_shifts + (long)f0 * 3, make_float3(1.0f, 1.0f, 1.0f));
+        r.forward(full, frames, ldf, frame_ids, f0, nf, r.bufA, r.bufB);
+        r.registration(full, r.bufA, tF_full, nullptr, f0, nf, rigid_shifts + (long)f0 * 3, make_float3(1.0f, 1.0f, 1.0f));
         // one shift per patch inside the window around the frame's rigid shift (:1562-1583), signs of :1596
-        forward(pat, frames, ldf, frame_ids, f0, nf * NP, bufA, bufB);
-        registration(pat, bufA, tF_patch, rigid_shifts, f0, nf * NP, patch_shifts + (long)f0 * NP * 3, make_float3(-1.0f, -1.0f, 1.0f));
+        r.forward(pat, frames, ldf, frame_ids, f0, nf * NP, r.bufA, r.bufB);
+        r.registration(pat, r.bufA, tF_patch, rigid_shifts, f0, nf * NP, patch_shifts + (long)f0 * NP * 3,
+                       make_float3(-1.0f, -1.0f, 1.0f));
     }
     return check_launch("dnmf_register_patches");
+}
+
+// frames per chunk of the rigid correction: two complex volumes per frame below 256 MB each
+static int mc_rigid_chunk(long P, int B) {
+    long c = (256L << 20) / (8 * P);
+    if (c > 65535) c = 65535;
+    if (c < 1) c = 1;
+    if (c > B) c = B;
+    return (int)c;
+}
+
+size_t dnmf_rigid_correct_workspace(int X, int Y, int Z, int B) {
+    using namespace dnmf;
+    if (X <= 0 || Y <= 0 || Z <= 0 || B <= 0) return 0;
+    const long P = (long)X * Y * Z;
+    const int Bc = mc_rigid_chunk(P, B);
+    int nmax = X > Y ? X : Y;
+    nmax = nmax > Z ? nmax : Z;
+    size_t b = 0;
+    b += 2 * mc_round((size_t)Bc * P * sizeof(float2)) + mc_round((size_t)P * sizeof(float2));
+    b += 2 * mc_round((size_t)Bc * MC_MW * Y * Z * sizeof(float2));
+    b += mc_round((size_t)Bc * MC_MW * MC_MW * MC_MW * sizeof(float2));
+    b += 2 * mc_round((size_t)Bc * 3 * MC_MW * sizeof(int)) + mc_round((size_t)Bc * 3 * sizeof(int));
+    b += mc_round((size_t)16384 * sizeof(int)) + mc_round(64) + mc_round(64) + mc_round((size_t)Bc * 3 * nmax * sizeof(int));
+    return b;
+}
+
+int dnmf_rigid_correct(const float *frames, long ldf, const int *frame_ids, int B, const float *tmpl, int X, int Y, int Z,
+                       const int *max_shifts, int upsample_factor, float add_to_movie, int border_nan, float *rigid_shifts,
+                       float *corrected, long ldc, float *tsum, int *tcount, void *workspace, size_t workspace_bytes,
+                       dnmf_stream_t stream) {
+    using namespace dnmf;
+    DNMF_REQUIRE(frames && tmpl && max_shifts && rigid_shifts && workspace, DNMF_E_NULL, "dnmf_rigid_correct: NULL argument");
+    DNMF_REQUIRE((tsum == nullptr) == (tcount == nullptr), DNMF_E_NULL, "dnmf_rigid_correct: tsum and tcount go together");
+    const long P = (long)X * Y * Z;
+    DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && B > 0 && ldf >= P && (!corrected || ldc >= P), DNMF_E_SHAPE,
+                 "dnmf_rigid_correct: X=%d Y=%d Z=%d B=%d ldf=%ld ldc=%ld", X, Y, Z, B, ldf, ldc);
+    DNMF_REQUIRE(upsample_factor >= 1 && (int)((upsample_factor * 3 + 1) / 2) <= MC_MW, DNMF_E_UNSUPPORTED,
+                 "dnmf_rigid_correct: upsample_factor %d (ceil(1.5 factor) <= %d)", upsample_factor, MC_MW);
+    const int S[3] = {X, Y, Z};
+    for (int d = 0; d < 3; ++d) {
+        DNMF_REQUIRE(S[d] * upsample_factor <= MC_MAXD, DNMF_E_UNSUPPORTED,
+                     "dnmf_rigid_correct: axis %d of %d voxels x upsample factor %d > %d", d, S[d], upsample_factor, MC_MAXD);
+        DNMF_REQUIRE(max_shifts[d] >= 0 && (S[d] <= MC_MW || 2 * max_shifts[d] <= MC_MW), DNMF_E_UNSUPPORTED,
+                     "dnmf_rigid_correct: search window of axis %d wider than %d shifts", d, MC_MW);
+    }
+    DNMF_REQUIRE(workspace_bytes >= dnmf_rigid_correct_workspace(X, Y, Z, B), DNMF_E_WORKSPACE,
+                 "dnmf_rigid_correct: workspace %zu < %zu bytes", workspace_bytes, dnmf_rigid_correct_workspace(X, Y, Z, B));
+    McRun r{};
+    r.st = (hipStream_t)stream, r.X = X, r.Y = Y, r.Z = Z, r.add = add_to_movie, r.uf = upsample_factor;
+    r.region = (upsample_factor * 3 + 1) / 2, r.max_dev = 0;
+    const int Bc = mc_rigid_chunk(P, B);
+    int nmax = X > Y ? X : Y;
+    nmax = nmax > Z ? nmax : Z;
+    char *at = static_cast<char *>(workspace);
+    auto take = [&](size_t bytes) { char *p = at; at += mc_round(bytes); return p; };
+    r.bufA = reinterpret_cast<float2 *>(take((size_t)Bc * P * sizeof(float2)));
+    r.bufB = reinterpret_cast<float2 *>(take((size_t)Bc * P * sizeof(float2)));
+    float2 *tF_full = reinterpret_cast<float2 *>(take((size_t)P * sizeof(float2)));
+    r.inv1 = reinterpret_cast<float2 *>(take((size_t)Bc * MC_MW * Y * Z * sizeof(float2)));
+    r.inv2 = reinterpret_cast<float2 *>(take((size_t)Bc * MC_MW * Y * Z * sizeof(float2)));
+    r.cc = reinterpret_cast<float2 *>(take((size_t)Bc * MC_MW * MC_MW * MC_MW * sizeof(float2)));
+    r.win = reinterpret_cast<int *>(take((size_t)Bc * 3 * MC_MW * sizeof(int)));
+    r.pos_up = reinterpret_cast<int *>(take((size_t)Bc * 3 * MC_MW * sizeof(int)));
+    r.peak = reinterpret_cast<int *>(take((size_t)Bc * 3 * sizeof(int)));
+    r.iota = reinterpret_cast<int *>(take((size_t)16384 * sizeof(int)));
+    int *starts = reinterpret_cast<int *>(take(64));
+    r.mshift = reinterpret_cast<int *>(take(64));
+    int *spos = reinterpret_cast<int *>(take((size_t)Bc * 3 * nmax * sizeof(int)));
+    {
+        hipError_t e = hipMemsetAsync(starts, 0, 3 * sizeof(int), r.st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r.mshift, max_shifts, 3 * sizeof(int), hipMemcpyHostToDevice, r.st);
+        DNMF_REQUIRE(e == hipSuccess, (int)e, "dnmf_rigid_correct: copy of max_shifts: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(mc_iota_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, r.st, r.iota, nmax);
+    McBoxes full;
+    full.n[0] = X, full.n[1] = Y, full.n[2] = Z, full.nbox = 1, full.start = starts;
+    r.forward(full, tmpl, 0, nullptr, 0, 1, tF_full, r.bufB);
+    for (int f0 = 0; f0 < B; f0 += Bc) {
+        const int nf = B - f0 < Bc ? B - f0 : Bc;
+        float *sh = rigid_shifts + (long)f0 * 3;
+        r.forward(full, frames, ldf, frame_ids, f0, nf, r.bufA, r.bufB);
+        r.registration(full, r.bufA, tF_full, nullptr, f0, nf, sh, make_float3(1.0f, 1.0f, 1.0f));
+        if (!corrected && !tsum) continue;
+        // apply_shifts_dft :1083-1097: the spectrum times exp(+2 pi i f s / n) per axis, inverse transform = the inverse
+        // DFT evaluated at the positions r + s_d, numerators (r uf + s_d uf) over uf (s_d is a multiple of 1 / uf)
+        hipLaunchKernelGGL(mc_shift_pos_kernel, dim3((unsigned)((3 * nmax + 255) / 256), (unsigned)nf), dim3(256), 0, r.st, sh, r.uf,
+                           full, nmax, spos);
+        McAxis a{};
+        a.bx = full, a.uf = r.uf, a.sign = 1, a.pos = spos, a.pos_item_stride = 3 * nmax, a.mode = 1;
+        a.in = r.bufA, a.outer = 1, a.n = X, a.inner = Y * Z, a.m = X, a.pos_off = 0, a.scale = 1.0f / (float)X, a.out = r.bufB;
+        mc_launch_axis(a, nf, 0, r.st);
+        a.in = r.bufB, a.outer = X, a.n = Y, a.inner = Z, a.m = Y, a.pos_off = nmax, a.scale = 1.0f / (float)Y, a.out = r.bufA;
+        mc_launch_axis(a, nf, 0, r.st);
+        a.in = r.bufA, a.outer = X * Y, a.n = Z, a.inner = 1, a.m = Z, a.pos_off = 2 * nmax, a.scale = 1.0f / (float)Z, a.out = r.bufB;
+        mc_launch_axis(a, nf, 0, r.st);
+        hipLaunchKernelGGL(mc_shifted_frames_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, r.st, r.bufB, nf, X, Y, Z, sh,
+                           add_to_movie, border_nan, corrected ? corrected + (long)f0 * ldc : nullptr, ldc, tsum, tcount);
+    }
+    return check_launch("dnmf_rigid_correct");
 }
 
 int dnmf_apply_shifts_points(const float *points, int K, const float *patch_shifts, int T, int NP, const float *centers, float *out,

@@ -603,6 +603,35 @@ def register_patches(frames, tmpl, sz, strides, overlaps, max_shifts, max_deviat
     return rigid, patch
 
 
+def rigid_correct(frames, tmpl, sz, max_shifts, upsample_factor=10, add_to_movie=0.0, border_nan=True, frame_ids=None,
+                  want_frames=False, tsum=None, tcount=None):
+    """K8, rigid pass.  frames (>=B, P) fp32 CUDA rows, tmpl (P) -> (rigid shifts (B,3) as register_translation_3d returns
+    them, corrected frames (B,P) or None, tsum (P) fp32, tcount (P) int32): the per-voxel sums and counts of the finite
+    corrected values are ADDED into ``tsum`` / ``tcount`` when given (a video walked in pieces), else start from zero."""
+    import ctypes
+    X, Y, Z = (int(s) for s in sz)
+    if frames.dtype != torch.float32 or frames.stride(-1) != 1 or not frames.is_cuda:
+        raise ValueError("rigid_correct: frames must be float32 CUDA with unit inner stride")
+    dev = frames.device
+    P = X * Y * Z
+    tm = _f32(tmpl.reshape(-1), "tmpl")
+    fid = _i32(frame_ids, dev) if frame_ids is not None else None
+    B = fid.numel() if fid is not None else frames.shape[0]
+    ms = (ctypes.c_int * 3)(*[int(v) for v in max_shifts])
+    lib = _lib.load()
+    ws = torch.empty((lib.dnmf_rigid_correct_workspace(X, Y, Z, B),), dtype=torch.uint8, device=dev)
+    rigid = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    out = torch.empty((B, P), dtype=torch.float32, device=dev) if want_frames else None
+    if tsum is None:
+        tsum, tcount = torch.zeros(P, dtype=torch.float32, device=dev), torch.zeros(P, dtype=torch.int32, device=dev)
+    with _timed("rigid_correct"):
+        rc = lib.dnmf_rigid_correct(frames.data_ptr(), frames.stride(0), _ptr(fid), B, tm.data_ptr(), X, Y, Z, ms,
+                                    int(upsample_factor), float(add_to_movie), 1 if border_nan else 0, rigid.data_ptr(),
+                                    _ptr(out), P, tsum.data_ptr(), tcount.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "dnmf_rigid_correct")
+    return rigid, out, tsum, tcount
+
+
 def apply_shifts_points(points, patch_shifts, centers):
     """points (K,3), patch_shifts (T,NP,3), centers (NP,3) -> (K,3,T) fp32 (MotionCorrect.apply_shifts_points)."""
     pts, sh, ce = _f32(points, "points"), _f32(patch_shifts, "patch_shifts"), _f32(centers, "centers")

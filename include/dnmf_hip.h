@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DNMF_ABI_VERSION 4
+#define DNMF_ABI_VERSION 5
 
 #define DNMF_OK 0
 #define DNMF_E_NULL (-1)      /* required pointer is NULL */
@@ -358,6 +358,19 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
                           const int *strides, const int *overlaps, const int *max_shifts, int max_deviation_rigid,
                           int upsample_factor, float add_to_movie, float *rigid_shifts, float *patch_shifts, void *workspace,
                           size_t workspace_bytes, dnmf_stream_t stream);
+/* Rigid correction of the frames against a template (tile_and_correct_3d :1518-1574 with max_deviation_rigid == 0, the
+ * pass motion_correct_batch_rigid :1770-1877 makes to build the template a piecewise-rigid pass starts from):
+ * rigid_shifts (B,3) as register_translation_3d returns them (the reference's shifts_rig holds their negatives, :1574);
+ * corrected (NULL or B rows of ldc floats): every frame moved by its shift through the phases of its spectrum
+ * (apply_shifts_dft :1028-1157, 3-D branch), minus add_to_movie; border_nan != 0: NaN where the shift brought in voxels
+ * from the other side (border_nan=True of the reference; its 'min' / 'copy' are not built); tsum / tcount (both NULL, or P
+ * floats / ints): += the finite corrected values and their number per voxel -- the nanmean of
+ * tile_and_correct_wrapper :2057 is tsum / tcount. */
+size_t dnmf_rigid_correct_workspace(int X, int Y, int Z, int B);
+int dnmf_rigid_correct(const float *frames, long ldf, const int *frame_ids, int B, const float *tmpl, int X, int Y, int Z,
+                       const int *max_shifts, int upsample_factor, float add_to_movie, int border_nan, float *rigid_shifts,
+                       float *corrected, long ldc, float *tsum, int *tcount, void *workspace, size_t workspace_bytes,
+                       dnmf_stream_t stream);
 /* apply_shifts_points :351-371: points (K,3), patch_shifts (T,NP,3) as above, centers (NP,3) = patch start + strides / 2 ->
  * out (K,3,T): out[k,0/1,t] = p - (s[t] - s[0]), out[k,2,t] = p + (s[t] - s[0]) with s the shifts of the patch whose
  * centre is nearest to point k. */

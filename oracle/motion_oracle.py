@@ -16,9 +16,14 @@ output for it.  What follows restates, from the source text, exactly the part `a
                            tile_and_correct_wrapper :2004-2060 with upsample_factor_fft=10
   apply_shifts_points      :351-371
 
-Not restated (not needed for the shifts): the corrected frames (`warp_sk`, `apply_shifts_dft`), the template refinement
-by a rigid pass (`motion_correct_batch_rigid` :1770-1877: the caller passes a template), the 2-D (cv2) functions, the
-`shifts_opencv=False` branch (cubic resize of the shift field, skimage).
+  bin_median_3d            :464-494                     the first template
+  apply_shifts_dft         :1028-1157 (3-D branch)      a frame moved by its rigid shift through its spectrum
+  rigid_correct_3d         tile_and_correct_3d :1518-1574 with max_deviation_rigid == 0
+  rigid_template           motion_correct_batch_rigid :1770-1877: the template a piecewise-rigid pass starts from when
+                           the caller gives none (MotionCorrect.motion_correct_pwrigid :298-301), and shifts_rig
+
+Not restated (not needed for the shifts): the piecewise-corrected frames (`warp_sk`), the 2-D (cv2) functions, the
+`shifts_opencv=False` branch (cubic resize of the shift field, skimage), border_nan 'min' / 'copy'.
 """
 from __future__ import annotations
 
@@ -79,13 +84,17 @@ def _zero_outside(cc, shifts_lb, shifts_ub, max_shifts):
     return cc
 
 
-def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_lb=None, shifts_ub=None, max_shifts=(10, 10, 10)):
-    """:648-797, space='real'.  Returns the shift vector (3,) float64."""
-    src_freq = np.fft.fftn(np.asarray(src_image, dtype=np.complex128))
-    target_freq = np.fft.fftn(np.asarray(target_image, dtype=np.complex128))
+def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_lb=None, shifts_ub=None, max_shifts=(10, 10, 10),
+                            full_output=False):
+    """:648-797, space='real'.  Returns the shift vector (3,) float64; with full_output also the spectrum of the source and
+    the phase difference, as the reference returns them (:797).  The images are rounded to complex64 first (:712-715); the
+    transforms are then taken in double precision, as the numpy of the reference's time did for any input."""
+    src_freq = np.fft.fftn(np.array(src_image, dtype=np.complex64).astype(np.complex128))
+    target_freq = np.fft.fftn(np.array(target_image, dtype=np.complex64).astype(np.complex128))
     shape = src_freq.shape
     image_product = src_freq * target_freq.conj()
     cross_correlation = np.fft.ifftn(image_product)
+    CCmax = cross_correlation.max()          # (numpy's max of a complex array: by real part, then imaginary, :727)
     new_cc = _zero_outside(np.abs(cross_correlation), shifts_lb, shifts_ub, max_shifts)
     maxima = np.unravel_index(np.argmax(new_cc), new_cc.shape)
     midpoints = np.array([np.fix(s // 2) for s in shape])
@@ -97,12 +106,95 @@ def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_l
         dftshift = np.fix(region / 2.0)
         offset = dftshift - shifts * upsample_factor
         cc = upsampled_dft(image_product.conj(), region, float(upsample_factor), offset).conj()
+        cc = cc / (src_freq.size * float(upsample_factor) ** 2)
         maxima = np.array(np.unravel_index(np.argmax(np.abs(cc)), cc.shape), dtype=np.float64) - dftshift
         shifts = shifts + maxima / upsample_factor
+        CCmax = cc.max()
     for d in range(3):
         if shape[d] == 1:
             shifts[d] = 0
+    if full_output:
+        return np.asarray(shifts, dtype=np.float64), src_freq, float(np.arctan2(CCmax.imag, CCmax.real))
     return np.asarray(shifts, dtype=np.float64)
+
+
+def apply_shifts_dft_3d(src_freq, shifts, diffphase, border_nan=True):
+    """apply_shifts_dft :1028-1157 for a 3-D spectrum: the image moved by `shifts` through the phases of its spectrum, real
+    part, NaN where the shift brought in voxels from the other side.  Kept from the reference: the first two shifts swap
+    places (:1083) so that shifts[0] rides on axis 1's frequencies Nr and shifts[1] on axis 0's Nc -- a correct pairing,
+    since the caller passes them in axis order -- but the NaN borders (:1104-1119) use the SWAPPED pair on axes 0 and 1."""
+    shifts = np.array(list(shifts[:-1][::-1]) + [shifts[-1]], dtype=np.float64)
+    nc, nr, nd = np.array(src_freq.shape, dtype=float)
+    Nr = np.fft.ifftshift(np.arange(-np.fix(nr / 2.), np.ceil(nr / 2.)))
+    Nc = np.fft.ifftshift(np.arange(-np.fix(nc / 2.), np.ceil(nc / 2.)))
+    Nd = np.fft.ifftshift(np.arange(-np.fix(nd / 2.), np.ceil(nd / 2.)))
+    Nr, Nc, Nd = np.meshgrid(Nr, Nc, Nd)
+    Greg = src_freq * np.exp(-1j * 2 * np.pi * (-shifts[0] * Nr / nr - shifts[1] * Nc / nc - shifts[2] * Nd / nd))
+    Greg = Greg.dot(np.exp(1j * diffphase))
+    new_img = np.real(np.fft.ifftn(Greg))
+    if border_nan is True:
+        max_h, max_w = np.ceil(np.maximum((0, 0), shifts[:2])).astype(int)
+        min_h, min_w = np.floor(np.minimum((0, 0), shifts[:2])).astype(int)
+        max_d = int(np.ceil(np.maximum(0, shifts[2])))
+        min_d = int(np.floor(np.minimum(0, shifts[2])))
+        new_img[:max_h, :] = np.nan
+        if min_h < 0:
+            new_img[min_h:, :] = np.nan
+        new_img[:, :max_w] = np.nan
+        if min_w < 0:
+            new_img[:, min_w:] = np.nan
+        new_img[:, :, :max_d] = np.nan
+        if min_d < 0:
+            new_img[:, :, min_d:] = np.nan
+    elif border_nan is not False:
+        raise NotImplementedError("border_nan 'min' / 'copy' are not restated")
+    return new_img
+
+
+def bin_median_3d(mat, window=10):
+    """:464-494 (exclude_nans=True): mean over groups of frames, median over the groups.  (The reshape to (window,
+    num_windows, ...) makes group j the frames j, j + num_windows, ...; kept.)"""
+    T, d1, d2, d3 = mat.shape
+    if T < window:
+        window = T
+    num_windows = int(T // window)
+    num_frames = num_windows * window
+    return np.nanmedian(np.nanmean(np.reshape(mat[:num_frames], (window, num_windows, d1, d2, d3)), axis=0), axis=0)
+
+
+def rigid_correct_3d(img, template, max_shifts, upsample_factor_fft=10, add_to_movie=0.0, border_nan=True):
+    """tile_and_correct_3d :1518-1574 with max_deviation_rigid == 0: (corrected frame, total shift) -- the frame moved
+    by its rigid shift, the shift with the sign flipped (:1573-1574)."""
+    img = np.asarray(img, dtype=np.float64) + add_to_movie
+    template = np.asarray(template, dtype=np.float64) + add_to_movie
+    s, sfr_freq, diffphase = register_translation_3d(img, template, upsample_factor=upsample_factor_fft, max_shifts=max_shifts,
+                                                     full_output=True)
+    new_img = apply_shifts_dft_3d(sfr_freq, (s[0], s[1], s[2]), diffphase, border_nan=border_nan)
+    return new_img - add_to_movie, (-s[0], -s[1], -s[2])
+
+
+def rigid_template(video, max_shifts, num_iter=1, template=None, add_to_movie=None, upsample_factor_fft=10, border_nan=True):
+    """motion_correct_batch_rigid :1770-1877 for a 3-D video (T, X, Y, Z) with splits = 1 (one chunk: every frame;
+    tile_and_correct_wrapper :2004-2060 walks the whole video whatever the chunk's indices are): (total_template, shifts
+    (T,3) with the flipped sign, corrected frames (T,X,Y,Z) float32)."""
+    video = np.asarray(video)
+    if template is None:
+        template = bin_median_3d(video)
+    if add_to_movie is None:
+        add_to_movie = -np.min(template)
+    add_to_movie = float(np.array(add_to_movie, dtype=np.float32))        # motion_correction_piecewise :2122
+    new_templ = template
+    for _ in range(num_iter):
+        old_templ = new_templ.copy()
+        mc = np.zeros(video.shape, dtype=np.float32)                       # :2027
+        shifts = []
+        for count, img in enumerate(video):
+            mc[count], sh = rigid_correct_3d(img, old_templ, max_shifts, upsample_factor_fft, add_to_movie, border_nan)
+            shifts.append(sh)
+        new_temp = np.nanmean(mc, 0)
+        new_temp[np.isnan(new_temp)] = np.nanmin(new_temp)
+        new_templ = np.nanmedian(np.stack([new_temp]), 0)
+    return new_templ, np.array(shifts, dtype=np.float64), mc
 
 
 def tile_shifts_3d(img, template, strides, overlaps, max_shifts, upsample_factor_fft=10, max_deviation_rigid=3,

@@ -122,7 +122,7 @@ def test_motioncorrect_front_end_and_apply_shifts_points(ops, MO):
     mc.motion_correct(template=template)
     assert len(mc.x_shifts_els) == len(mc.y_shifts_els) == len(mc.z_shifts_els) == T
     NP = len(MO.sliding_window_3d(sz, mc.overlaps, mc.strides))
-    assert mc.x_shifts_els[0].shape == (NP,) and len(mc.shifts_rig) == T and mc.border_to_0 >= 1
+    assert mc.x_shifts_els[0].shape == (NP,) and mc.border_to_0 >= 1
     points = np.random.RandomState(1).rand(K, 3) * np.array(sz)
     P_T = mc.apply_shifts_points(video, points)
     ref = MO.apply_shifts_points(np.stack(mc.x_shifts_els), np.stack(mc.y_shifts_els), np.stack(mc.z_shifts_els), sz, mc.overlaps,
@@ -138,3 +138,73 @@ def test_motioncorrect_front_end_and_apply_shifts_points(ops, MO):
     assert tuple(dn.fp.A.shape) == (*sz, K)
     with pytest.raises(NotImplementedError):
         MotionCorrect(video, is3D=False)
+
+
+@pytest.mark.parametrize("sz,max_shifts", [([48, 40, 2], (5, 5, 1)), ([40, 36, 5], (6, 4, 2)), ([64, 64, 1], (6, 6, 0))])
+def test_rigid_correction_vs_oracle(ops, MO, sz, max_shifts):
+    """dnmf_rigid_correct against the restatement of tile_and_correct_3d's rigid branch + apply_shifts_dft (:1518-1574,
+    :1028-1157): same shifts (to a bin of 0.1 voxel), the frames moved through their spectra equal to 2e-4 of the frame's
+    range where both are finite (fp32 transforms against complex128), the same NaN borders -- including the reference's
+    pairing of the border of axis 0 with the shift of axis 1 -- and the NaN-aware sums behind the next template."""
+    T = 6
+    video, template, _, _ = synthetic_video(sz, T, 40, seed=sum(sz) + 1, piecewise=False)
+    add = float(np.float32(-video.min()))
+    ref_frames, ref_shifts = [], []
+    for img in video:
+        f, sh = MO.rigid_correct_3d(img, template, max_shifts, 10, add, True)
+        ref_frames.append(f), ref_shifts.append(sh)
+    ref_frames, ref_shifts = np.array(ref_frames), -np.array(ref_shifts)
+    frames = torch.from_numpy(video.reshape(T, -1)).cuda()
+    rigid, out, tsum, tcount = ops.rigid_correct(frames, torch.from_numpy(template).cuda(), sz, max_shifts, 10, add, True, want_frames=True)
+    rigid, out = rigid.cpu().numpy(), out.cpu().numpy().reshape(T, *sz)
+    same = np.abs(rigid - ref_shifts).max(1) < 1e-3
+    assert same.mean() >= 0.8 and np.abs(rigid - ref_shifts).max() <= 0.1 + 1e-3
+    assert np.abs(ref_shifts[:, :2]).max() > 1.0
+    scale = float(video.max() - video.min())
+    for t in np.flatnonzero(same):
+        np.testing.assert_array_equal(np.isnan(out[t]), np.isnan(ref_frames[t]), err_msg=str(t))
+        ok = ~np.isnan(out[t])
+        assert ok.any()
+        np.testing.assert_allclose(out[t][ok], ref_frames[t][ok], rtol=0, atol=2e-4 * scale, err_msg=str(t))
+    np.testing.assert_array_equal(tcount.cpu().numpy().reshape(sz), (~np.isnan(out)).sum(0))
+    np.testing.assert_allclose(tsum.cpu().numpy().reshape(sz), np.nansum(out, 0), rtol=1e-5, atol=1e-5)
+    # a frame moved by its own shift lines up with the template: the registration of the corrected frame is ~zero
+    filled = np.where(np.isnan(out), template[None], out).astype(np.float32)
+    r2, _, _, _ = ops.rigid_correct(torch.from_numpy(filled.reshape(T, -1)).cuda(), torch.from_numpy(template).cuda(), sz, max_shifts,
+                                    10, add, True)
+    assert np.abs(r2.cpu().numpy()).max() <= 0.3
+
+
+def test_motioncorrect_without_a_template(ops, MO):
+    """template=None (reference :298-301): the rigid pre-pass builds the template -- the binned median, one rigid
+    correction of every frame against it, the NaN-aware mean of the moved frames -- and the piecewise pass starts from
+    there.  Against oracle.rigid_template on the same video; then the class with pw_rigid=False (rigid only)."""
+    from dnmf_amd.Demix.MotionCorrect import MotionCorrect
+    sz, T = [48, 40, 2], 23            # 23 frames: two bins of ten, three frames left out of the first template
+    video, _, _, _ = synthetic_video(sz, T, 30, seed=21, piecewise=False)
+    templ, shifts, moved = MO.rigid_template(video, (5, 5, 1), add_to_movie=-float(video.min()))
+    mc = MotionCorrect(video, max_shifts=(5, 5, 1), strides=(16, 12, 1), overlaps=(8, 8, 1), is3D=True, pw_rigid=False,
+                       save_corrected=True)
+    mc.motion_correct()
+    got = np.array(mc.shifts_rig)
+    assert got.shape == (T, 3)
+    bins = np.abs(got - shifts) * 10
+    assert bins.max() <= 1.0 + 1e-3 and (bins < 1e-3).mean() >= 0.85
+    scale = float(video.max() - video.min())
+    # (a frame whose shift landed in the neighbouring bin moves the mean by 0.1 voxel / T of a gradient)
+    np.testing.assert_allclose(mc.total_template_rig, templ, rtol=0, atol=5e-3 * scale)
+    assert np.abs(mc.total_template_rig - templ).mean() <= 2e-4 * scale
+    assert mc.mc[0].shape == (*sz, T) and mc.border_to_0 >= 1
+    same = np.flatnonzero(bins.max(1) < 1e-3)
+    t = int(same[0])
+    ok = ~np.isnan(moved[t])
+    np.testing.assert_allclose(mc.mc[0][..., t][ok], moved[t][ok], atol=2e-4 * scale)
+    first = mc._bin_median_3d(torch.from_numpy(video.reshape(T, -1)).cuda()).cpu().numpy().reshape(sz)
+    np.testing.assert_allclose(first, MO.bin_median_3d(video), rtol=1e-6, atol=1e-7)
+    # the piecewise pass on top of it
+    mc2 = MotionCorrect(video, max_shifts=(5, 5, 1), strides=(16, 12, 1), overlaps=(8, 8, 1), is3D=True, pw_rigid=True)
+    mc2.motion_correct()
+    np.testing.assert_allclose(mc2.total_template_els.cpu().numpy(), mc.total_template_rig, atol=1e-6)
+    sx, sy, sz_, _ = MO.pw_rigid_shifts(video, mc.total_template_rig, (16, 12, 1), (8, 8, 1), (5, 5, 1), 10, 3, -float(video.min()))
+    pb = np.abs(np.stack(mc2.x_shifts_els) - sx) * 10
+    assert pb.max() <= 1.0 + 1e-3 and (pb < 1e-3).mean() >= 0.95

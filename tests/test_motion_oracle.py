@@ -62,3 +62,35 @@ def test_tile_shifts_and_points():
     np.testing.assert_allclose(P_T[:, :, 0], pts)
     # a point follows the video: P_T = p - (shift[t] - shift[0]) with shift = -displacement
     assert 0.3 < P_T[0, 0, 1] - pts[0, 0] < 1.7 and 0.3 < P_T[1, 1, 2] - pts[1, 1] < 2.0
+
+
+def test_rigid_pass_of_the_oracle():
+    """apply_shifts_dft undoes the shift register_translation_3d finds (an integer shift: exactly a roll; the NaN borders as
+    the reference places them -- the border of axis 0 from the shift of axis 1 and the other way round, on the side the
+    2-D code would use, which is not where the roll wrapped around), the binned
+    median follows the reference's reshape, and rigid_template returns a template every frame lines up with."""
+    from oracle import motion_oracle as MO
+    tm = smooth_volume((40, 36, 4), 2)
+    img = np.roll(tm, (3, -2, 1), axis=(0, 1, 2))
+    s, freq, phase = MO.register_translation_3d(img, tm, 10, max_shifts=(6, 6, 2), full_output=True)
+    np.testing.assert_allclose(s, [3, -2, 1], atol=1e-6)
+    assert abs(phase) < 1e-6
+    moved = MO.apply_shifts_dft_3d(freq, s, phase, border_nan=False)
+    np.testing.assert_allclose(moved, tm, atol=1e-5)   # new(r) = img(r + s): the displacement s is undone
+    nan = np.isnan(MO.apply_shifts_dft_3d(freq, s, phase, border_nan=True))
+    # shifts (3, -2, 1) -> swapped (-2, 3, 1): axis 0 loses its LAST two rows, axis 1 its FIRST three columns, axis 2 its first slice
+    expect = np.zeros(tm.shape, bool)
+    expect[-2:], expect[:, :3], expect[:, :, :1] = True, True, True
+    np.testing.assert_array_equal(nan, expect)
+    mat = np.arange(25 * 2 * 1 * 1, dtype=float).reshape(25, 2, 1, 1)
+    # 25 frames: two bins; bin j = mean of frames j, j + 2, ..., j + 18; the median of two bins is their mean
+    np.testing.assert_allclose(MO.bin_median_3d(mat)[:, 0, 0], [np.mean([mat[j::2][:10, i, 0, 0].mean() for j in range(2)]) for i in range(2)])
+    video = np.array([fourier_shift(tm, sh) for sh in [(0, 0, 0), (1.2, 0.7, 0), (-2.0, 1.5, 0), (0.4, -0.6, 0)] * 3], dtype=np.float32)
+    templ, shifts, mc = MO.rigid_template(video, (5, 5, 1))
+    assert templ.shape == tm.shape and not np.isnan(templ).any() and mc.dtype == np.float32
+    # every corrected frame registers to the new template with (almost) no shift left
+    for f in mc[:4]:
+        left = MO.register_translation_3d(np.where(np.isnan(f), templ, f), templ, 10, max_shifts=(5, 5, 1))
+        assert np.abs(left).max() <= 0.2, left
+    # total shifts differ between frames by minus the displacement differences
+    np.testing.assert_allclose(shifts[1] - shifts[0], [-1.2, -0.7, 0], atol=0.11)

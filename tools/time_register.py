@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time K8 (dnmf_register_patches) on a synthetic video: python tools/time_register.py [size] [Z] [T] [stride] [overlap]"""
+"""Time K8 (dnmf_register_patches, dnmf_rigid_correct) on a synthetic video: python tools/time_register.py [size] [Z] [T] [stride] [overlap]"""
 import os
 import sys
 import time
@@ -26,6 +26,13 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"{sz} T={T} patches {tuple(dims)} of {tuple(s + o for s, o in zip(st, ov))}: {1e3 * dt:.1f} ms = {T / dt:.0f} frames/s", flush=True)
+    for i in range(3):   # the rigid pass behind template=None: shifts, every frame moved through its spectrum, sums for the template
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.rigid_correct(frames, tmpl, sz, ms, 10, 0.0, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{sz} T={T} rigid correction: {1e3 * dt:.1f} ms = {T / dt:.0f} frames/s", flush=True)
 
 
 if __name__ == "__main__":
