@@ -347,10 +347,13 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
     };
     if (!(inv_m < 1e3f)) {   // (block-uniform)
         if (valid)
-            for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (long)gx * YZ + u);
+            for (int gx = x_first; gx < x_end; ++gx) mark(todo + (long)b * vol.P + (unsigned)(gx * YZ + u));
         return;
     }
+    // (voxel indices are 32-bit here: the host sends volumes of 2^29 voxels or more to the one-point-per-thread kernel)
     const float *y = frames + (long)(frame_ids ? frame_ids[b] : b) * ldf;
+    float *out_b = out + (long)b * ldo;
+    unsigned char *todo_b = todo + (long)b * vol.P;
     float bt[30], b2[30];
     load_beta(beta, T, times[b], bt);
     double_beta(bt, b2);
@@ -358,14 +361,15 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
     const int S[3] = {vol.X, vol.Y, vol.Z};
     const int lane = (int)(threadIdx.x & 63);
     const float eps = 1e-4f + 1e-5f * (float)max(vol.X, max(vol.Y, vol.Z));
+    const float tq = (((1.0f - 1e-3f) / inv_m - 3.0f * eps) / 1.00001f) * 0.99999f;   // (d0 + rho < tq: radius < 1)
     float v[3] = {(float)x_first * k[0], (float)gy * k[1], HASZ ? (float)gz * k[2] : 0.0f};
     // corner positions kept from the last row: the upper x-face of its cell (voxel row kept_x, columns kept_y / + 1, slices
     // kept_z / + 1)
     int kept_x = -1000, kept_y = -1000, kept_z = -1000;
     float kept[NF][3];
     for (int gx = x_first; gx < x_end; ++gx) {
-        const long g = (long)gx * YZ + u;
-        unsigned char *flag = todo + (long)b * vol.P + g;
+        const unsigned g = (unsigned)(gx * YZ + u);
+        unsigned char *flag = todo_b + g;
         const float gf[3] = {(float)gx, (float)gy, (float)gz};
         float res[3] = {0.0f, 0.0f, 0.0f};
         auto residual = [&]() {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         {
             float keep[3] = {v[0], v[1], v[2]};
 #pragma unroll
-            for (int d = 0; d < ND; ++d) vc[d] = fminf(fmaxf(v[d], 0.0f), (float)(S[d] - 1)), v[d] = vc[d];
+            for (int d = 0; d < ND; ++d) vc[d] = __builtin_amdgcn_fmed3f(v[d], 0.0f, (float)(S[d] - 1)), v[d] = vc[d];   // (one instruction)
             residual();   // at the clamped point (the stretch bound holds between points of the volume)
             if (HASZ) {
                 v[0] = keep[0] + k[0], v[1] = keep[1], v[2] = keep[2];    // the next row starts here
@@ -402,7 +406,6 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                 v[0] += k[0];
             }
         }
-        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
         int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
 #pragma unroll
         for (int d = 0; d < ND; ++d) c0[d] = min((int)vc[d], max(S[d] - 2, 0)), c1[d] = min(c0[d] + 1, S[d] - 1);
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         kept_x = c1[0], kept_y = c0[1], kept_z = c0[2];
         auto corner_index = [&](int i) {
             const int x = (i >= NF) ? c1[0] : c0[0], yy = (i & (HASZ ? 2 : 1)) ? c1[1] : c0[1], zz = (HASZ && (i & 1)) ? c1[2] : c0[2];
-            return ((long)x * vol.Y + yy) * vol.Z + zz;
+            return (x * vol.Y + yy) * vol.Z + zz;
         };
         float dist[NC];
         float d1 = __builtin_inff();
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         // float64 among the candidates within the margin of the smallest (usually one: then its fp32 distance decides)
         const float lim = d1 * 1.000002f + 1e-30f;
         double best = 1e300;
-        long arg = 0;
+        int arg = 0;
         int nclose = 0;
 #pragma unroll
         for (int i = 0; i < NC; ++i) nclose += dist[i] <= lim ? 1 : 0;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                 if (!(dist[i] <= lim)) continue;
                 const double dx = (double)pos[i][0] - gx, dy = (double)pos[i][1] - gy, dz = HASZ ? (double)pos[i][2] - gz : 0.0;
                 const double d = dx * dx + dy * dy + dz * dz;
-                const long idx = corner_index(i);
+                const int idx = corner_index(i);
                 if (d < best || (d == best && idx < arg)) best = d, arg = idx;
             }
         }
@@ -465,9 +468,18 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         // volume this is d0 instead of d0 + rho (rho ~ 0); for a lattice point whose pre-image LEFT the volume (c points
         // outwards, rho = how far, d0 barely larger: the nearest voxel sits next to v on the face) it is ~1/2 voxel where the
         // triangle inequality gives 2 rho -- boxes of (4 rho + 1)^2 voxels along every edge the warp moves inwards.
-        const float d0f = sqrtf((float)best);
         int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         bool inside = true, far = false;
+        // Z == 1: the usual case settled without a square root -- a radius below 1 is the cell whatever the point's place
+        // in it, and  r < 1  <=  d0 + rho < tq  <=  best < (tq - (|c_x| + |c_y|))^2  (tq: per frame, set before the walk)
+        bool quick = false;
+        if (!HASZ) {
+            const float t = tq - (fabsf(res[0]) + fabsf(res[1]));
+            quick = t > 0.0f && (float)best < t * t * 0.999999f;   // (NaN: false)
+        }
+        if (!quick) {
+        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
+        const float d0f = sqrtf((float)best);
         auto window = [&](float R) {   // the radii for |a| <= R, the voxels within them, whether those are the cell's
             const float r = R * inv_m + 1e-3f;
             far = !(r < (float)IW_RMAX);   // also NaN: for the exhaustive kernel
@@ -506,6 +518,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
             const float R2 = (sigma + sqrtf(fmaf(sigma, sigma, fmaxf((D0 - rlo) * (D0 + rlo), 0.0f)))) * 1.00001f + eps;
             if (R2 < R1) window(R2);   // (NaN: the first window stays)
         }
+        }
         if (far && valid) mark(flag);
 #ifdef DNMF_IW_NOBOX   // timing study only (wrong results): what the kernel costs without the box
         inside = true;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                 const int n = (__builtin_amdgcn_readlane(hi[0], src) - l0 + 1) * n1 * n2;
                 const int sy = __builtin_amdgcn_readlane(gy, src), sz = __builtin_amdgcn_readlane(gz, src);
                 double cb = 1e300;
-                long ca = 0;
+                int ca = 0;
                 for (int c = lane; c < n; c += 64) {
                     const int t = HASZ ? c / n2 : c, zz = HASZ ? l2 + (c - t * n2) : 0;
                     const int xo = t / n1, x = l0 + xo, yy = l1 + (t - xo * n1);
@@ -540,13 +553,13 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                     iwarp_position_t<HASZ, FAST>(bt, vol, x, yy, zz, px, py, pz);
                     const double ex = (double)px - gx, ey = (double)py - sy, ez = HASZ ? (double)pz - sz : 0.0;
                     const double dd = ex * ex + ey * ey + ez * ez;
-                    const long idx = ((long)x * vol.Y + yy) * vol.Z + zz;
+                    const int idx = (x * vol.Y + yy) * vol.Z + zz;
                     if (dd < cb || (dd == cb && idx < ca)) cb = dd, ca = idx;
                 }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
                     const double od = __shfl_xor(cb, off);
-                    const long oa = __shfl_xor(ca, off);
+                    const int oa = __shfl_xor(ca, off);
                     if (od < cb || (od == cb && oa < ca)) cb = od, ca = oa;
                 }
                 if (lane == src) best = cb, arg = ca;
@@ -566,12 +579,12 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                         if (!(d <= bestf * 1.000002f + 1e-30f)) continue;
                         const double ex = (double)sx - gx, ey = (double)sy - gy, ez = HASZ ? (double)sz - gz : 0.0;
                         const double dd = ex * ex + ey * ey + ez * ez;
-                        const long idx = ((long)x * vol.Y + yy) * vol.Z + zz;
+                        const int idx = (x * vol.Y + yy) * vol.Z + zz;
                         if (dd < best || (dd == best && idx < arg)) best = dd, arg = idx, bestf = fminf(bestf, d);
                     }
         }
         if (valid && !far) {
-            out[(long)b * ldo + g] = y[arg];
+            out_b[g] = y[(unsigned)arg];
             *flag = 0;
         }
     }
@@ -683,7 +696,8 @@ int dnmf_image_iwarp(const float *frames, long ldf, const int *frame_ids, int X,
 #define DNMF_IW_ROWS_LAUNCH(HZ, FD)                                                                                              \
     hipLaunchKernelGGL((image_iwarp_rows_kernel<HZ, FD>), rgrid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T, times,  \
                        stretch, sc, out, ldo, todo, marked, nyb)
-        if (X == 1 || Y == 1) {   // an axis of one voxel (its hk is infinite): the one-point-per-thread kernel marks every point
+        if (X == 1 || Y == 1 || vol.P >= (1L << 29)) {   // an axis of one voxel (its hk is infinite: every point is marked), or voxel
+                                                          // indices beyond the rows kernel's 32 bits: one point per thread
             if (Z > 1)
                 hipLaunchKernelGGL(image_iwarp_window_kernel<true>, grid, dim3(256), 0, st, frames, ldf, frame_ids, vol, beta, T,
                                    times, stretch, sc, out, ldo, todo, marked);
