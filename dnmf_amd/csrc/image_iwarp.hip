@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256) void image_iwarp_window_kernel(const float *__
 // point of the odd slice is equidistant from both slices (:83 scales by sz, not sz - 1); lowest voxel index among equals.
 // Points that need more than their cell (or a frame without a usable stretch bound) are handled exactly as in the window
 // kernel: the box in float64, or a mark for the exhaustive kernel.
+// An UPPER bound of sqrt(x) for the radii (x >= 0 or NaN): the hardware's square root (one instruction, 1 ulp) rounded up
+// generously, instead of the correctly rounded sequence of ~15 instructions sqrtf compiles to; the absolute term covers
+// arguments below the normal range, which the instruction may flush to zero.
+__device__ __forceinline__ float iw_sqrt_up(float x) { return fmaf(__builtin_amdgcn_sqrtf(x), 1.000001f, 1e-18f); }
+
 #ifndef DNMF_IW_ROWS
 #define DNMF_IW_ROWS 8
 #endif
@@ -478,15 +483,15 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
             quick = t > 0.0f && (float)best < t * t * 0.999999f;   // (NaN: false)
         }
         if (!quick) {
-        const float rho = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
-        const float d0f = sqrtf((float)best);
+        const float rho = iw_sqrt_up(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);   // (upper bounds both)
+        const float d0f = iw_sqrt_up((float)best);
         auto window = [&](float R) {   // the radii for |a| <= R, the voxels within them, whether those are the cell's
             const float r = R * inv_m + 1e-3f;
             far = !(r < (float)IW_RMAX);   // also NaN: for the exhaustive kernel
             float rad[3] = {r, r, r};
             if (HASZ) {   // the anisotropic radii (iwarp_min_stretch); never larger than the isotropic one
                 const float Rp = R * an_df, md = an_mu * fabsf(vc[2] - rintf(vc[2]));
-                const float inplane = sqrtf(fmaxf((Rp - md) * (Rp + md), 0.0f)) * 1.00001f;
+                const float inplane = iw_sqrt_up(fmaxf((Rp - md) * (Rp + md), 0.0f)) * 1.00001f;
                 const float rz = Rp * an_imu * 1.00001f;
                 const float rxy = (inplane + an_t * rz) * an_im2 * 1.00001f + 1e-3f;
                 rad[0] = rad[1] = fminf(r, rxy);   // (NaN or inf constants: fminf keeps r)
@@ -513,9 +518,9 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                 wp = fmaf(wv, wv, wp);
             }
             const float drift_s = an[4], m_fro = an[5];
-            const float sigma = ((sqrtf(wp) + 2.0f * m_fro * eps) * 1.0001f + drift_s * (rho + eps)) * inv_m * 1.00001f;
-            const float D0 = d0f * 1.00001f + 2.0f * eps, rlo = fmaxf(rho * 0.99999f - eps, 0.0f);
-            const float R2 = (sigma + sqrtf(fmaf(sigma, sigma, fmaxf((D0 - rlo) * (D0 + rlo), 0.0f)))) * 1.00001f + eps;
+            const float sigma = ((iw_sqrt_up(wp) + 2.0f * m_fro * eps) * 1.0001f + drift_s * (rho + eps)) * inv_m * 1.00001f;
+            const float D0 = d0f * 1.00001f + 2.0f * eps, rlo = fmaxf(rho * 0.99999f - eps, 0.0f);   // (0.99999: also below the true rho)
+            const float R2 = (sigma + iw_sqrt_up(fmaf(sigma, sigma, fmaxf((D0 - rlo) * (D0 + rlo), 0.0f)))) * 1.00001f + eps;
             if (R2 < R1) window(R2);   // (NaN: the first window stays)
         }
         }
