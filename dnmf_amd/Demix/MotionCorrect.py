@@ -19,7 +19,7 @@ on its own (``shifts_rig``, ``total_template_rig``, ``templates_rig``; the corre
 ``save_corrected=True``: it is as large as the video).
 
 Not offered (``NotImplementedError``): the piecewise-corrected movie, 2-D (cv2) registration, ``shifts_opencv=False`` (cubic
-resize of the shift field), ``border_nan`` 'min' / 'copy', memory-mapped files, ``dview``, ``gSig_filt``.
+resize of the shift field), memory-mapped files, ``dview``, ``gSig_filt``.
 
 Parity: the reference module cannot be imported in the build container (cv2, skimage and ``past`` are absent, ``np.int``
 is gone from numpy 2) and ships no fixture; this class is checked against ``oracle/motion_oracle.py``, a numpy restatement
@@ -61,8 +61,8 @@ class MotionCorrect(object):
         self.shifts_opencv = True
         self.min_mov = min_mov
         self.nonneg_movie = nonneg_movie
-        if border_nan not in (True, False):
-            raise NotImplementedError("MotionCorrect: border_nan 'min' / 'copy' are not built")
+        if border_nan not in (True, False, 'min', 'copy'):
+            raise ValueError(f"MotionCorrect: border_nan {border_nan!r}")
         self.border_nan = border_nan
         self.niter_rig = int(niter_rig)
         if splits_rig != 1 or splits_els != 1 or num_splits_to_process_rig is not None or num_splits_to_process_els is not None:
@@ -134,7 +134,7 @@ class MotionCorrect(object):
                 parts, moved = [], []
                 for f0 in range(0, frames.shape[0], step):
                     r, out, tsum, tcount = ops.rigid_correct(frames[f0:f0 + step], tmpl, sz, self.max_shifts, self.upsample_factor_fft,
-                                                             add_to_movie=add, border_nan=bool(self.border_nan),
+                                                             add_to_movie=add, border_nan=self.border_nan,
                                                              want_frames=self.save_corrected and last, tsum=tsum, tcount=tcount)
                     parts.append(r)
                     if out is not None:

@@ -150,6 +150,11 @@ __global__ __launch_bounds__(256) void mc_axis_kernel(McAxis a) {
     }
 }
 
+__global__ void mc_fill_kernel(float *p, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // pos[r] = r for r < n (the forward DFT's positions)
 __global__ void mc_iota_kernel(int *pos, int n) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,14 +314,39 @@ __global__ void mc_shift_pos_kernel(const float *shifts, int uf, McBoxes bx, int
     pos[((long)item * 3 + d) * nmax + r] = r < bx.n[d] ? r * uf + sn : INT_MIN;
 }
 
-// apply_shifts_dft :1098-1119 and tile_and_correct_3d :1573: real part of the shifted frames minus add_to_movie, NaN where the
-// shift brought in voxels from the other side -- with the reference's pairing: the border of axis 0 follows the shift
-// of axis 1 and the other way round (:1083 swaps the first two shifts for the frequencies, :1104-1113 use the swapped pair on
-// the axes in order).  Written to `corrected` and / or added into the per-voxel sums and counts of the finite values (the
-// nanmean of tile_and_correct_wrapper :2057).  The factor exp(i diffphase) of :1097 is left out: diffphase is the argument of
-// the correlation's peak value, zero up to rounding for real images (1e-8 here), and it multiplies a real image.
+// smallest finite real part of every frame of (nf, P) complex values -> fmin[f] (initialised to +inf by the caller): the
+// np.nanmin of border_nan='min' (:1121)
+__global__ __launch_bounds__(256) void mc_frame_min_kernel(const float2 *img, long P, float *fmin) {
+    const int f = blockIdx.y;
+    float m = __builtin_inff();
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < P; g += (long)gridDim.x * 256) m = fminf(m, img[(long)f * P + g].x);
+    __shared__ float sm[256];
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = fminf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    // (float order = order of the bit patterns for values of one sign; both signs: two atomics on the two orders)
+    if (threadIdx.x == 0) {
+        const float v = sm[0];
+        if (v >= 0.0f)
+            atomicMin(reinterpret_cast<int *>(fmin + f), __float_as_int(v));
+        else
+            atomicMax(reinterpret_cast<unsigned *>(fmin + f), __float_as_uint(v));
+    }
+}
+
+// apply_shifts_dft :1098-1145 and tile_and_correct_3d :1573: real part of the shifted frames minus add_to_movie, and the
+// border where the shift brought in voxels from the other side -- with the reference's pairing: the border of axis 0
+// follows the shift of axis 1 and the other way round (:1083 swaps the first two shifts for the frequencies, :1104-1113 use the
+// swapped pair on the axes in order).  border: 0 leave, 1 NaN (border_nan=True), 2 the frame's smallest value ('min'),
+// 3 the nearest row / column / slice inside ('copy': the reference copies axis by axis, which composes to clamping each
+// index).  Written to `corrected` and / or added into the per-voxel sums and counts of the finite values (the nanmean of
+// tile_and_correct_wrapper :2057).  The factor exp(i diffphase) of :1097 is left out: diffphase is the argument of the
+// correlation's peak value, zero up to rounding for real images (1e-8 here), and it multiplies a real image.
 __global__ __launch_bounds__(256) void mc_shifted_frames_kernel(const float2 *img, int nf, int X, int Y, int Z, const float *shifts,
-                                                                float add, int border_nan, float *corrected, long ldc,
+                                                                float add, int border, const float *fmin, float *corrected, long ldc,
                                                                 float *tsum, int *tcount) {
     const long P = (long)X * Y * Z;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +356,7 @@ __global__ __launch_bounds__(256) void mc_shifted_frames_kernel(const float2 *im
     int cnt = 0;
     for (int f = 0; f < nf; ++f) {
         float v = img[(long)f * P + g].x - add;
-        if (border_nan) {
+        if (border) {
             const float s0 = shifts[3 * f], s1 = shifts[3 * f + 1], s2 = shifts[3 * f + 2];
             const int max_h = (int)ceilf(fmaxf(0.0f, s1)), min_h = (int)floorf(fminf(0.0f, s1));
             const int max_w = (int)ceilf(fmaxf(0.0f, s0)), min_w = (int)floorf(fminf(0.0f, s0));
@@ -334,7 +364,13 @@ __global__ __launch_bounds__(256) void mc_shifted_frames_kernel(const float2 *im
             // python: a[:max_h] and, for min_h < 0, a[min_h:] (slices clip to the axis)
             const bool out = x < max_h || (min_h < 0 && x >= max(X + min_h, 0)) || y < max_w || (min_w < 0 && y >= max(Y + min_w, 0)) ||
                              z < max_d || (min_d < 0 && z >= max(Z + min_d, 0));
-            if (out) v = __builtin_nanf("");
+            if (out && border == 1) v = __builtin_nanf("");
+            if (out && border == 2) v = fmin[f] - add;
+            if (out && border == 3) {
+                const int xs = min(max(x, max_h), X + min_h - 1), ys = min(max(y, max_w), Y + min_w - 1),
+                          zs = min(max(z, max_d), Z + min_d - 1);
+                v = img[(long)f * P + ((long)min(max(xs, 0), X - 1) * Y + min(max(ys, 0), Y - 1)) * Z + min(max(zs, 0), Z - 1)].x - add;
+            }
         }
         if (corrected) corrected[(long)f * ldc + g] = v;
         if (v == v) acc += v, ++cnt;
@@ -568,6 +604,7 @@ size_t dnmf_rigid_correct_workspace(int X, int Y, int Z, int B) {
     b += mc_round((size_t)Bc * MC_MW * MC_MW * MC_MW * sizeof(float2));
     b += 2 * mc_round((size_t)Bc * 3 * MC_MW * sizeof(int)) + mc_round((size_t)Bc * 3 * sizeof(int));
     b += mc_round((size_t)16384 * sizeof(int)) + mc_round(64) + mc_round(64) + mc_round((size_t)Bc * 3 * nmax * sizeof(int));
+    b += mc_round((size_t)Bc * sizeof(float));
     return b;
 }
 
@@ -583,6 +620,7 @@ int dnmf_rigid_correct(const float *frames, long ldf, const int *frame_ids, int 
                  "dnmf_rigid_correct: X=%d Y=%d Z=%d B=%d ldf=%ld ldc=%ld", X, Y, Z, B, ldf, ldc);
     DNMF_REQUIRE(upsample_factor >= 1 && (int)((upsample_factor * 3 + 1) / 2) <= MC_MW, DNMF_E_UNSUPPORTED,
                  "dnmf_rigid_correct: upsample_factor %d (ceil(1.5 factor) <= %d)", upsample_factor, MC_MW);
+    DNMF_REQUIRE(border_nan >= 0 && border_nan <= 3, DNMF_E_UNSUPPORTED, "dnmf_rigid_correct: border_nan %d (0 .. 3)", border_nan);
     const int S[3] = {X, Y, Z};
     for (int d = 0; d < 3; ++d) {
         DNMF_REQUIRE(S[d] * upsample_factor <= MC_MAXD, DNMF_E_UNSUPPORTED,
@@ -613,6 +651,7 @@ int dnmf_rigid_correct(const float *frames, long ldf, const int *frame_ids, int 
     int *starts = reinterpret_cast<int *>(take(64));
     r.mshift = reinterpret_cast<int *>(take(64));
     int *spos = reinterpret_cast<int *>(take((size_t)Bc * 3 * nmax * sizeof(int)));
+    float *fmin = reinterpret_cast<float *>(take((size_t)Bc * sizeof(float)));
     {
         hipError_t e = hipMemsetAsync(starts, 0, 3 * sizeof(int), r.st);
         if (e == hipSuccess) e = hipMemcpyAsync(r.mshift, max_shifts, 3 * sizeof(int), hipMemcpyHostToDevice, r.st);
@@ -640,8 +679,13 @@ int dnmf_rigid_correct(const float *frames, long ldf, const int *frame_ids, int 
         mc_launch_axis(a, nf, 0, r.st);
         a.in = r.bufA, a.outer = X * Y, a.n = Z, a.inner = 1, a.m = Z, a.pos_off = 2 * nmax, a.scale = 1.0f / (float)Z, a.out = r.bufB;
         mc_launch_axis(a, nf, 0, r.st);
+        if (border_nan == 2) {
+            hipLaunchKernelGGL(mc_fill_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, r.st, fmin, nf, __builtin_inff());
+            const unsigned nb = (unsigned)(P / 4096 > 256 ? 256 : (P + 4095) / 4096);
+            hipLaunchKernelGGL(mc_frame_min_kernel, dim3(nb, (unsigned)nf), dim3(256), 0, r.st, r.bufB, P, fmin);
+        }
         hipLaunchKernelGGL(mc_shifted_frames_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, r.st, r.bufB, nf, X, Y, Z, sh,
-                           add_to_movie, border_nan, corrected ? corrected + (long)f0 * ldc : nullptr, ldc, tsum, tcount);
+                           add_to_movie, border_nan, fmin, corrected ? corrected + (long)f0 * ldc : nullptr, ldc, tsum, tcount);
     }
     return check_launch("dnmf_rigid_correct");
 }

@@ -603,6 +603,9 @@ def register_patches(frames, tmpl, sz, strides, overlaps, max_shifts, max_deviat
     return rigid, patch
 
 
+_BORDER = {False: 0, True: 1, 'min': 2, 'copy': 3}     # border_nan of apply_shifts_dft (MotionCorrect.py:1098-1145)
+
+
 def rigid_correct(frames, tmpl, sz, max_shifts, upsample_factor=10, add_to_movie=0.0, border_nan=True, frame_ids=None,
                   want_frames=False, tsum=None, tcount=None):
     """K8, rigid pass.  frames (>=B, P) fp32 CUDA rows, tmpl (P) -> (rigid shifts (B,3) as register_translation_3d returns
@@ -626,7 +629,7 @@ def rigid_correct(frames, tmpl, sz, max_shifts, upsample_factor=10, add_to_movie
         tsum, tcount = torch.zeros(P, dtype=torch.float32, device=dev), torch.zeros(P, dtype=torch.int32, device=dev)
     with _timed("rigid_correct"):
         rc = lib.dnmf_rigid_correct(frames.data_ptr(), frames.stride(0), _ptr(fid), B, tm.data_ptr(), X, Y, Z, ms,
-                                    int(upsample_factor), float(add_to_movie), 1 if border_nan else 0, rigid.data_ptr(),
+                                    int(upsample_factor), float(add_to_movie), _BORDER[border_nan], rigid.data_ptr(),
                                     _ptr(out), P, tsum.data_ptr(), tcount.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "dnmf_rigid_correct")
     return rigid, out, tsum, tcount

@@ -362,8 +362,9 @@ int dnmf_register_patches(const float *frames, long ldf, const int *frame_ids, i
  * pass motion_correct_batch_rigid :1770-1877 makes to build the template a piecewise-rigid pass starts from):
  * rigid_shifts (B,3) as register_translation_3d returns them (the reference's shifts_rig holds their negatives, :1574);
  * corrected (NULL or B rows of ldc floats): every frame moved by its shift through the phases of its spectrum
- * (apply_shifts_dft :1028-1157, 3-D branch), minus add_to_movie; border_nan != 0: NaN where the shift brought in voxels
- * from the other side (border_nan=True of the reference; its 'min' / 'copy' are not built); tsum / tcount (both NULL, or P
+ * (apply_shifts_dft :1028-1157, 3-D branch), minus add_to_movie; border_nan: what goes where the shift brought in voxels
+ * from the other side -- 0 nothing (False of the reference), 1 NaN (True), 2 the frame's smallest value ('min'), 3 the
+ * nearest row / column / slice inside ('copy'); tsum / tcount (both NULL, or P
  * floats / ints): += the finite corrected values and their number per voxel -- the nanmean of
  * tile_and_correct_wrapper :2057 is tsum / tcount. */
 size_t dnmf_rigid_correct_workspace(int X, int Y, int Z, int B);

@@ -23,7 +23,7 @@ output for it.  What follows restates, from the source text, exactly the part `a
                            the caller gives none (MotionCorrect.motion_correct_pwrigid :298-301), and shifts_rig
 
 Not restated (not needed for the shifts): the piecewise-corrected frames (`warp_sk`), the 2-D (cv2) functions, the
-`shifts_opencv=False` branch (cubic resize of the shift field, skimage), border_nan 'min' / 'copy'.
+`shifts_opencv=False` branch (cubic resize of the shift field, skimage).
 """
 from __future__ import annotations
 
@@ -147,7 +147,35 @@ def apply_shifts_dft_3d(src_freq, shifts, diffphase, border_nan=True):
         if min_d < 0:
             new_img[:, :, min_d:] = np.nan
     elif border_nan is not False:
-        raise NotImplementedError("border_nan 'min' / 'copy' are not restated")
+        max_h, max_w = np.ceil(np.maximum((0, 0), shifts[:2])).astype(int)
+        min_h, min_w = np.floor(np.minimum((0, 0), shifts[:2])).astype(int)
+        max_d = int(np.ceil(np.maximum(0, shifts[2])))
+        min_d = int(np.floor(np.minimum(0, shifts[2])))
+        if border_nan == 'min':                      # :1120-1131
+            min_ = np.nanmin(new_img)
+            new_img[:max_h, :] = min_
+            if min_h < 0:
+                new_img[min_h:, :] = min_
+            new_img[:, :max_w] = min_
+            if min_w < 0:
+                new_img[:, min_w:] = min_
+            new_img[:, :, :max_d] = min_
+            if min_d < 0:
+                new_img[:, :, min_d:] = min_
+        elif border_nan == 'copy':                   # :1132-1145
+            new_img[:max_h] = new_img[max_h]
+            if min_h < 0:
+                new_img[min_h:] = new_img[min_h - 1]
+            if max_w > 0:
+                new_img[:, :max_w] = new_img[:, max_w, np.newaxis]
+            if min_w < 0:
+                new_img[:, min_w:] = new_img[:, min_w - 1, np.newaxis]
+            if max_d > 0:
+                new_img[:, :, :max_d] = new_img[:, :, max_d, np.newaxis]
+            if min_d < 0:
+                new_img[:, :, min_d:] = new_img[:, :, min_d - 1, np.newaxis]
+        else:
+            raise ValueError(border_nan)
     return new_img
 
 

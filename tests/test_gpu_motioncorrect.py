@@ -208,3 +208,25 @@ def test_motioncorrect_without_a_template(ops, MO):
     sx, sy, sz_, _ = MO.pw_rigid_shifts(video, mc.total_template_rig, (16, 12, 1), (8, 8, 1), (5, 5, 1), 10, 3, -float(video.min()))
     pb = np.abs(np.stack(mc2.x_shifts_els) - sx) * 10
     assert pb.max() <= 1.0 + 1e-3 and (pb < 1e-3).mean() >= 0.95
+
+
+@pytest.mark.parametrize("border", [False, "min", "copy"])
+def test_rigid_correction_border_modes(ops, MO, border):
+    """border_nan False / 'min' / 'copy' of apply_shifts_dft (:1098-1145) against the restatement."""
+    sz, max_shifts, T = [40, 36, 5], (6, 4, 2), 5
+    video, template, _, _ = synthetic_video(sz, T, 40, seed=77, piecewise=False)
+    add = float(np.float32(-video.min()))
+    ref = [MO.rigid_correct_3d(img, template, max_shifts, 10, add, border) for img in video]
+    frames = torch.from_numpy(video.reshape(T, -1)).cuda()
+    rigid, out, tsum, tcount = ops.rigid_correct(frames, torch.from_numpy(template).cuda(), sz, max_shifts, 10, add, border, want_frames=True)
+    rigid, out = rigid.cpu().numpy(), out.cpu().numpy().reshape(T, *sz)
+    scale = float(video.max() - video.min())
+    checked = 0
+    for t in range(T):
+        if np.abs(rigid[t] + np.array(ref[t][1])).max() > 1e-3:      # (ref holds the flipped sign)
+            continue
+        assert not np.isnan(out[t]).any()
+        np.testing.assert_allclose(out[t], ref[t][0], rtol=0, atol=3e-4 * scale, err_msg=str(t))
+        checked += 1
+    assert checked >= 3
+    assert int(tcount.min()) == T

@@ -94,3 +94,22 @@ def test_rigid_pass_of_the_oracle():
         assert np.abs(left).max() <= 0.2, left
     # total shifts differ between frames by minus the displacement differences
     np.testing.assert_allclose(shifts[1] - shifts[0], [-1.2, -0.7, 0], atol=0.11)
+
+
+def test_border_modes_of_the_oracle():
+    from oracle import motion_oracle as MO
+    tm = smooth_volume((24, 20, 4), 3)
+    img = np.roll(tm, (2, -3, 1), axis=(0, 1, 2))
+    s, freq, phase = MO.register_translation_3d(img, tm, 10, max_shifts=(4, 4, 2), full_output=True)
+    plain = MO.apply_shifts_dft_3d(freq, s, phase, border_nan=False)
+    nan = np.isnan(MO.apply_shifts_dft_3d(freq, s, phase, border_nan=True))
+    mn = MO.apply_shifts_dft_3d(freq, s, phase, border_nan='min')
+    np.testing.assert_allclose(mn[nan], plain.min())
+    np.testing.assert_allclose(mn[~nan], plain[~nan])
+    cp = MO.apply_shifts_dft_3d(freq, s, phase, border_nan='copy')
+    np.testing.assert_allclose(cp[~nan], plain[~nan])
+    # swapped shifts (-3, 2, 1): axis 0 copies row X - 4 into its last three rows, axis 1 column 2 into its first two
+    np.testing.assert_allclose(cp[-1, 5, 2], plain[-4, 5, 2])
+    np.testing.assert_allclose(cp[6, 0, 2], plain[6, 2, 2])
+    np.testing.assert_allclose(cp[6, 5, 0], plain[6, 5, 1])
+    np.testing.assert_allclose(cp[-1, 0, 0], plain[-4, 2, 1])       # a corner: every index clamped
