@@ -436,26 +436,30 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
             return (x * vol.Y + yy) * vol.Z + zz;
         };
         float dist[NC];
-        float d1 = __builtin_inff();
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const float dx = pos[i][0] - gf[0], dy = pos[i][1] - gf[1], dz = HASZ ? pos[i][2] - gf[2] : 0.0f;
             dist[i] = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-            d1 = fminf(d1, dist[i]);
         }
-        // float64 among the candidates within the margin of the smallest (usually one: then its fp32 distance decides)
+        // the smallest fp32 distance and its corner, without branches (selects); then: is any other corner within the margin?
+        float d1 = dist[0];
+        int wi = 0;
+#pragma unroll
+        for (int i = 1; i < NC; ++i) {
+            const bool lt = dist[i] < d1;
+            d1 = lt ? dist[i] : d1, wi = lt ? i : wi;
+        }
         const float lim = d1 * 1.000002f + 1e-30f;
-        double best = 1e300;
-        int arg = 0;
         int nclose = 0;
 #pragma unroll
         for (int i = 0; i < NC; ++i) nclose += dist[i] <= lim ? 1 : 0;
-        if (nclose == 1) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (dist[i] <= lim) arg = corner_index(i);
-            best = (double)d1;
-        } else {   // (NaN distances: nclose == 0, best stays huge and the radius test below marks the point)
+        double best = 1e300;
+        int arg = 0;
+        if (nclose == 1) {   // the usual case: the fp32 ranking decides
+            const int wx = wi >= NF ? c1[0] : c0[0], wy = (wi & (HASZ ? 2 : 1)) ? c1[1] : c0[1], wz = (HASZ && (wi & 1)) ? c1[2] : c0[2];
+            arg = (wx * vol.Y + wy) * vol.Z + wz;
+        } else {   // float64 among the candidates within the margin; lowest voxel index among equals.  (NaN distances:
+                   // nclose == 0, best stays huge and the radius test below marks the point)
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 if (!(dist[i] <= lim)) continue;
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                 if (d < best || (d == best && idx < arg)) best = d, arg = idx;
             }
         }
+        const float bestf = nclose == 1 ? d1 : (float)best;   // (the float64 value itself is formed where a box needs it)
         // R bounds |a|, a = s(v*) - s(v) for the nearest voxel v*: by the triangle inequality d0 + rho; and (round 3) by the
         // angle between a and c = g - s(v):  |a - c| <= d0  gives  |a|^2 <= d0^2 - rho^2 + 2 a.c,  and with a = (M + E)(v* - v),
         // |E|_F <= drift_s, |v* - v| <= |a| / m:  a.c <= |a| sigma,  sigma = (|w+| + drift_s rho) / m,  where w = M^T c and
@@ -480,11 +485,12 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         bool quick = false;
         if (!HASZ) {
             const float t = tq - (fabsf(res[0]) + fabsf(res[1]));
-            quick = t > 0.0f && (float)best < t * t * 0.999999f;   // (NaN: false)
+            quick = t > 0.0f && bestf < t * t * 0.999999f;   // (NaN: false)
         }
         if (!quick) {
+        if (nclose == 1) best = (double)d1;
         const float rho = iw_sqrt_up(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);   // (upper bounds both)
-        const float d0f = iw_sqrt_up((float)best);
+        const float d0f = iw_sqrt_up(bestf);
         auto window = [&](float R) {   // the radii for |a| <= R, the voxels within them, whether those are the cell's
             const float r = R * inv_m + 1e-3f;
             far = !(r < (float)IW_RMAX);   // also NaN: for the exhaustive kernel
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         } else if (box) {
             // voxels beyond the cell are ranked in fp32 against the cell's result; a voxel takes part in the float64
             // comparison only when its fp32 distance is within the margin of the best so far
-            float bestf = (float)best;
+            float bf = (float)best;
             for (int x = lo[0]; x <= hi[0]; ++x)
                 for (int yy = lo[1]; yy <= hi[1]; ++yy)
                     for (int zz = lo[2]; zz <= hi[2]; ++zz) {
@@ -581,11 +587,11 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
                         iwarp_position_t<HASZ, FAST>(bt, vol, x, yy, zz, sx, sy, sz);
                         const float dx = sx - gf[0], dy = sy - gf[1], dz = HASZ ? sz - gf[2] : 0.0f;
                         const float d = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                        if (!(d <= bestf * 1.000002f + 1e-30f)) continue;
+                        if (!(d <= bf * 1.000002f + 1e-30f)) continue;
                         const double ex = (double)sx - gx, ey = (double)sy - gy, ez = HASZ ? (double)sz - gz : 0.0;
                         const double dd = ex * ex + ey * ey + ez * ez;
                         const int idx = (x * vol.Y + yy) * vol.Z + zz;
-                        if (dd < best || (dd == best && idx < arg)) best = dd, arg = idx, bestf = fminf(bestf, d);
+                        if (dd < best || (dd == best && idx < arg)) best = dd, arg = idx, bf = fminf(bf, d);
                     }
         }
         if (valid && !far) {
