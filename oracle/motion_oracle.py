@@ -120,63 +120,44 @@ def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_l
 
 def apply_shifts_dft_3d(src_freq, shifts, diffphase, border_nan=True):
     """apply_shifts_dft :1028-1157 for a 3-D spectrum: the image moved by `shifts` through the phases of its spectrum, real
-    part, NaN where the shift brought in voxels from the other side.  Kept from the reference: the first two shifts swap
-    places (:1083) so that shifts[0] rides on axis 1's frequencies Nr and shifts[1] on axis 0's Nc -- a correct pairing,
-    since the caller passes them in axis order -- but the NaN borders (:1104-1119) use the SWAPPED pair on axes 0 and 1."""
-    shifts = np.array(list(shifts[:-1][::-1]) + [shifts[-1]], dtype=np.float64)
-    nc, nr, nd = np.array(src_freq.shape, dtype=float)
-    Nr = np.fft.ifftshift(np.arange(-np.fix(nr / 2.), np.ceil(nr / 2.)))
-    Nc = np.fft.ifftshift(np.arange(-np.fix(nc / 2.), np.ceil(nc / 2.)))
-    Nd = np.fft.ifftshift(np.arange(-np.fix(nd / 2.), np.ceil(nd / 2.)))
-    Nr, Nc, Nd = np.meshgrid(Nr, Nc, Nd)
-    Greg = src_freq * np.exp(-1j * 2 * np.pi * (-shifts[0] * Nr / nr - shifts[1] * Nc / nc - shifts[2] * Nd / nd))
-    Greg = Greg.dot(np.exp(1j * diffphase))
-    new_img = np.real(np.fft.ifftn(Greg))
-    if border_nan is True:
-        max_h, max_w = np.ceil(np.maximum((0, 0), shifts[:2])).astype(int)
-        min_h, min_w = np.floor(np.minimum((0, 0), shifts[:2])).astype(int)
-        max_d = int(np.ceil(np.maximum(0, shifts[2])))
-        min_d = int(np.floor(np.minimum(0, shifts[2])))
-        new_img[:max_h, :] = np.nan
-        if min_h < 0:
-            new_img[min_h:, :] = np.nan
-        new_img[:, :max_w] = np.nan
-        if min_w < 0:
-            new_img[:, min_w:] = np.nan
-        new_img[:, :, :max_d] = np.nan
-        if min_d < 0:
-            new_img[:, :, min_d:] = np.nan
-    elif border_nan is not False:
-        max_h, max_w = np.ceil(np.maximum((0, 0), shifts[:2])).astype(int)
-        min_h, min_w = np.floor(np.minimum((0, 0), shifts[:2])).astype(int)
-        max_d = int(np.ceil(np.maximum(0, shifts[2])))
-        min_d = int(np.floor(np.minimum(0, shifts[2])))
-        if border_nan == 'min':                      # :1120-1131
-            min_ = np.nanmin(new_img)
-            new_img[:max_h, :] = min_
-            if min_h < 0:
-                new_img[min_h:, :] = min_
-            new_img[:, :max_w] = min_
-            if min_w < 0:
-                new_img[:, min_w:] = min_
-            new_img[:, :, :max_d] = min_
-            if min_d < 0:
-                new_img[:, :, min_d:] = min_
-        elif border_nan == 'copy':                   # :1132-1145
-            new_img[:max_h] = new_img[max_h]
-            if min_h < 0:
-                new_img[min_h:] = new_img[min_h - 1]
-            if max_w > 0:
-                new_img[:, :max_w] = new_img[:, max_w, np.newaxis]
-            if min_w < 0:
-                new_img[:, min_w:] = new_img[:, min_w - 1, np.newaxis]
-            if max_d > 0:
-                new_img[:, :, :max_d] = new_img[:, :, max_d, np.newaxis]
-            if min_d < 0:
-                new_img[:, :, min_d:] = new_img[:, :, min_d - 1, np.newaxis]
+    part, and the border where the shift brought in voxels from the other side: NaN (True), the image's smallest value
+    ('min'), the nearest row / column / slice inside ('copy'), or left alone (False).
+
+    What is kept from the reference.  It swaps the first two shifts (:1083) and pairs the swapped shifts[0] with the
+    frequencies of axis 1 and shifts[1] with those of axis 0 (:1085-1091): every axis is ramped by its own shift, the phase
+    terms added in the order axis 1, axis 0, axis 2.  The borders (:1098-1145) then use the SWAPPED pair on the axes in
+    order: the border of axis 0 follows the shift of axis 1 and the other way round; axis 2 its own."""
+    own = [float(shifts[0]), float(shifts[1]), float(shifts[2])]
+    n = src_freq.shape
+    freq = [np.fft.ifftshift(np.arange(-np.fix(n[d] / 2.), np.ceil(n[d] / 2.))).reshape([-1 if e == d else 1 for e in range(3)])
+            for d in range(3)]
+    turns = None
+    for d in (1, 0, 2):
+        term = own[d] * freq[d] / float(n[d])
+        turns = term if turns is None else turns + term
+    moved = src_freq * np.exp(1j * 2 * np.pi * turns)
+    moved = moved * np.exp(1j * diffphase)
+    out = np.real(np.fft.ifftn(moved))
+    if border_nan is False:
+        return out
+    swapped = [own[1], own[0], own[2]]
+    fill = np.nanmin(out) if border_nan == 'min' else np.nan
+    if border_nan not in (True, 'min', 'copy'):
+        raise ValueError(border_nan)
+    for d in range(3):
+        head = int(np.ceil(max(0.0, swapped[d])))            # rows [:head] ...
+        tail = int(np.floor(min(0.0, swapped[d])))           # ... and, when negative, rows [tail:]
+        view = np.moveaxis(out, d, 0)
+        if border_nan == 'copy':
+            if head > 0 or d == 0:                           # (:1133 copies into axis 0 unconditionally: a no-op for head == 0)
+                view[:head] = view[head]
+            if tail < 0:
+                view[tail:] = view[tail - 1]
         else:
-            raise ValueError(border_nan)
-    return new_img
+            view[:head] = fill
+            if tail < 0:
+                view[tail:] = fill
+    return out
 
 
 def bin_median_3d(mat, window=10):
