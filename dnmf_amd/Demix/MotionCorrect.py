@@ -18,8 +18,12 @@ moved frames as the template of the piecewise pass -- K8 ``dnmf_rigid_correct``.
 on its own (``shifts_rig``, ``total_template_rig``, ``templates_rig``; the corrected movie in ``mc`` only with
 ``save_corrected=True``: it is as large as the video).
 
-Not offered (``NotImplementedError``): the piecewise-corrected movie, 2-D (cv2) registration, ``shifts_opencv=False`` (cubic
-resize of the shift field), memory-mapped files, ``dview``, ``gSig_filt``.
+2-D videos (``is3D=False``, (T, X, Y); ``register_translation`` ``:801-1024``, ``tile_and_correct`` ``:1272-1418``) are
+registered as one slice of the same kernels: ``motion_correct_pwrigid(template=...)`` fills ``x_shifts_els`` /
+``y_shifts_els``.  (``apply_shifts_points`` is 3-D in the reference too.)
+
+Not offered (``NotImplementedError``): the piecewise-corrected movie (``cv2.remap``), the 2-D rigid correction
+(``cv2.warpAffine``), ``shifts_opencv=False`` (cubic resize of the shift field), memory-mapped files, ``dview``, ``gSig_filt``.
 
 Parity: the reference module cannot be imported in the build container (cv2, skimage and ``past`` are absent, ``np.int``
 is gone from numpy 2) and ships no fixture; this class is checked against ``oracle/motion_oracle.py``, a numpy restatement
@@ -42,8 +46,6 @@ class MotionCorrect(object):
                  nonneg_movie=True, gSig_filt=None, use_cuda=False, border_nan=True, pw_rigid=False, num_frames_split=80,
                  var_name_hdf5='mov', is3D=True, indices=(slice(None), slice(None)), save_corrected=False):
         ops._lib.load()   # fail here, loudly, if the HIP library is not built
-        if not is3D:
-            raise NotImplementedError("MotionCorrect: only the 3-D functions are built (apply_shifts_points is 3-D)")
         if not shifts_opencv:
             raise NotImplementedError("MotionCorrect: shifts_opencv=False (cubic resize of the shift field) is not built")
         if gSig_filt is not None or dview is not None:
@@ -51,11 +53,18 @@ class MotionCorrect(object):
         if type(video) is not list:
             video = [video]
         self.video = video
+        self.is3D = bool(is3D)
         self.max_shifts = tuple(int(v) for v in max_shifts)
         self.strides = tuple(int(v) for v in strides)
         self.overlaps = tuple(int(v) for v in overlaps)
-        if not (len(self.max_shifts) == len(self.strides) == len(self.overlaps) == 3):
-            raise ValueError("MotionCorrect: max_shifts, strides and overlaps need three entries (x, y, z)")
+        nd = 3 if self.is3D else 2
+        if not self.is3D:
+            # 2-D videos (T, X, Y) -- register_translation :801-1024, tile_and_correct :1272-1418 -- run as one slice of the
+            # 3-D kernels: a third axis of one voxel has no window and a zero shift.  (A 2-D call may still pass the 3-entry
+            # defaults of this class: their third entries are dropped.)
+            self.max_shifts, self.strides, self.overlaps = self.max_shifts[:2], self.strides[:2], self.overlaps[:2]
+        if not (len(self.max_shifts) == len(self.strides) == len(self.overlaps) == nd):
+            raise ValueError(f"MotionCorrect: max_shifts, strides and overlaps need {nd} entries")
         self.max_deviation_rigid = int(max_deviation_rigid)
         self.upsample_factor_grid = upsample_factor_grid
         self.shifts_opencv = True
@@ -70,15 +79,21 @@ class MotionCorrect(object):
                                       "in pieces of its own")
         self.save_corrected = bool(save_corrected)
         self.pw_rigid = bool(pw_rigid)
-        self.is3D = True
         self.upsample_factor_fft = 10     # tile_and_correct_wrapper :2029-2037
 
-    @staticmethod
-    def _frames(video):
-        """(T, X, Y, Z) numpy / torch -> (T, P) fp32 CUDA rows and the volume size."""
+    def _p3(self):
+        """strides, overlaps, max_shifts with three entries (one slice for a 2-D video: window 1, no shift)."""
+        if self.is3D:
+            return self.strides, self.overlaps, self.max_shifts
+        return self.strides + (1,), self.overlaps + (0,), self.max_shifts + (0,)
+
+    def _frames(self, video):
+        """(T, X, Y, Z) -- (T, X, Y) for is3D=False -- numpy / torch -> (T, P) fp32 CUDA rows and the volume size (Z = 1)."""
         v = torch.as_tensor(np.asarray(video) if not torch.is_tensor(video) else video)
-        if v.dim() != 4:
-            raise ValueError(f"MotionCorrect: a video is (T, X, Y, Z), got {tuple(v.shape)}")
+        if not self.is3D and v.dim() == 3:
+            v = v[..., None]
+        if v.dim() != 4 or (not self.is3D and v.shape[3] != 1):
+            raise ValueError(f"MotionCorrect: a video is (T, X, Y, Z) (is3D) or (T, X, Y), got {tuple(v.shape)}")
         sz = [int(s) for s in v.shape[1:]]
         return v.to(device, torch.float32).reshape(v.shape[0], -1).contiguous(), sz
 
@@ -88,8 +103,8 @@ class MotionCorrect(object):
             self.min_mov = min(float(torch.as_tensor(v).min()) for v in self.video)     # (:193-195: of the first video)
         if self.pw_rigid:
             self.motion_correct_pwrigid(template=template)
-            b0 = np.ceil(np.max([np.max(np.abs(self.x_shifts_els)), np.max(np.abs(self.y_shifts_els)),
-                                 np.max(np.abs(self.z_shifts_els))]))
+            b0 = np.ceil(np.max([np.max(np.abs(self.x_shifts_els)), np.max(np.abs(self.y_shifts_els))] +
+                                ([np.max(np.abs(self.z_shifts_els))] if self.is3D else [])))
         else:
             self.motion_correct_rigid(template=template)
             b0 = np.ceil(np.max(np.abs(self.shifts_rig)))
@@ -114,6 +129,11 @@ class MotionCorrect(object):
         """Reference :213-258 -> motion_correct_batch_rigid :1770-1877 (3-D, one chunk): fills ``total_template_rig``,
         ``templates_rig``, ``shifts_rig`` (one (x, y, z) tuple per frame, the registration's shift with its sign flipped,
         :1574) and -- only with ``save_corrected=True`` -- ``mc`` (one (X, Y, Z, T) array per video)."""
+        if not self.is3D:
+            # (the reference moves 2-D frames with cv2.warpAffine when shifts_opencv is set, :1349-1354, and its own 2-D start
+            # without a template calls a method numpy arrays do not have, :1828)
+            raise NotImplementedError("MotionCorrect.motion_correct_rigid: the 2-D rigid correction (cv2.warpAffine) is not built; "
+                                      "2-D videos: motion_correct_pwrigid(template=...)")
         self.total_template_rig = template
         self.templates_rig, self.shifts_rig, self.mc = [], [], []
         for video_cur in self.video:
@@ -154,8 +174,11 @@ class MotionCorrect(object):
         """Reference :260-328: fills ``x_shifts_els``, ``y_shifts_els``, ``z_shifts_els`` (one (NP,) array per frame),
         ``shifts_rig`` (the rigid shift of every frame), ``coord_shifts_els`` (the patch grid indices) and
         ``total_template_els``."""
-        self.x_shifts_els, self.y_shifts_els, self.z_shifts_els = [], [], []
+        self.x_shifts_els, self.y_shifts_els = [], []
+        if self.is3D:
+            self.z_shifts_els = []
         self.coord_shifts_els = []
+        strides, overlaps, max_shifts = self._p3()
         for video_cur in self.video:
             frames, sz = self._frames(video_cur)
             if self.min_mov is None:
@@ -166,17 +189,19 @@ class MotionCorrect(object):
             else:
                 tmpl = torch.as_tensor(np.asarray(template) if not torch.is_tensor(template) else template).to(
                     device, torch.float32).reshape(-1)
-            self.total_template_els = tmpl.view(*sz)
-            rigid, patch = ops.register_patches(frames, tmpl, sz, self.strides, self.overlaps, self.max_shifts,
+            self.total_template_els = tmpl.view(*sz) if self.is3D else tmpl.view(*sz[:2])
+            rigid, patch = ops.register_patches(frames, tmpl, sz, strides, overlaps, max_shifts,
                                                 self.max_deviation_rigid, self.upsample_factor_fft,
                                                 add_to_movie=-self.min_mov)
-            dims, starts = ops.patch_grid(sz, self.strides, self.overlaps)
-            grid = [tuple(int(v) for v in np.unravel_index(q, dims)) for q in range(len(starts))]
+            dims, starts = ops.patch_grid(sz, strides, overlaps)
+            nd = 3 if self.is3D else 2
+            grid = [tuple(int(v) for v in np.unravel_index(q, dims))[:nd] for q in range(len(starts))]
             p = patch.cpu().numpy()
             for t in range(p.shape[0]):
                 self.x_shifts_els.append(p[t, :, 0].copy())
                 self.y_shifts_els.append(p[t, :, 1].copy())
-                self.z_shifts_els.append(p[t, :, 2].copy())
+                if self.is3D:
+                    self.z_shifts_els.append(p[t, :, 2].copy())
                 self.coord_shifts_els.append(grid)
             self._patch_shifts = patch                       # (T, NP, 3) on the GPU, for apply_shifts_points
 
@@ -192,6 +217,9 @@ class MotionCorrect(object):
     def apply_shifts_points(self, video, points):
         """Reference :351-371: ``P_T`` (K, 3, T) float64 numpy -- point k in frame t, moved by the shifts of the patch whose
         centre is nearest to it, relative to frame 0."""
+        if not self.is3D:
+            raise NotImplementedError("MotionCorrect.apply_shifts_points is a 3-D function (reference :351-371: z_shifts_els, "
+                                      "sliding_window_3d); register 2-D videos as (T, X, Y, 1) with is3D=True")
         v = np.asarray(video.shape) if hasattr(video, "shape") else None
         T, sz = int(v[0]), [int(s) for s in v[1:]]
         pts = torch.as_tensor(np.asarray(points)).to(device, torch.float32).contiguous()
@@ -201,6 +229,8 @@ class MotionCorrect(object):
 
     def apply_shifts_frame(self, video, points, t):
         """Reference :330-349: the points moved by frame t's shifts (no reference frame, all three signs +)."""
+        if not self.is3D:
+            raise NotImplementedError("MotionCorrect.apply_shifts_frame is a 3-D function (reference :330-349)")
         from scipy.spatial import distance
         v = np.asarray(video.shape)
         sz = [int(s) for s in v[1:]]

@@ -22,7 +22,11 @@ output for it.  What follows restates, from the source text, exactly the part `a
   rigid_template           motion_correct_batch_rigid :1770-1877: the template a piecewise-rigid pass starts from when
                            the caller gives none (MotionCorrect.motion_correct_pwrigid :298-301), and shifts_rig
 
-Not restated (not needed for the shifts): the piecewise-corrected frames (`warp_sk`), the 2-D (cv2) functions, the
+  register_translation     :801-1024 (2-D)              as the 3-D restatement on an (X, Y, 1) array
+  tile_shifts_2d           tile_and_correct :1272-1418 up to `total_shifts`, sliding_window :1160-1188
+
+Not restated (not needed for the shifts): the piecewise-corrected frames (`warp_sk`, cv2.remap), the rigidly corrected 2-D
+frames (cv2.warpAffine), the
 `shifts_opencv=False` branch (cubic resize of the shift field, skimage).
 """
 from __future__ import annotations
@@ -85,12 +89,13 @@ def _zero_outside(cc, shifts_lb, shifts_ub, max_shifts):
 
 
 def register_translation_3d(src_image, target_image, upsample_factor=1, shifts_lb=None, shifts_ub=None, max_shifts=(10, 10, 10),
-                            full_output=False):
+                            full_output=False, to_complex64=True):
     """:648-797, space='real'.  Returns the shift vector (3,) float64; with full_output also the spectrum of the source and
     the phase difference, as the reference returns them (:797).  The images are rounded to complex64 first (:712-715); the
     transforms are then taken in double precision, as the numpy of the reference's time did for any input."""
-    src_freq = np.fft.fftn(np.array(src_image, dtype=np.complex64).astype(np.complex128))
-    target_freq = np.fft.fftn(np.array(target_image, dtype=np.complex64).astype(np.complex128))
+    first = np.complex64 if to_complex64 else np.complex128
+    src_freq = np.fft.fftn(np.array(src_image, dtype=first).astype(np.complex128))
+    target_freq = np.fft.fftn(np.array(target_image, dtype=first).astype(np.complex128))
     shape = src_freq.shape
     image_product = src_freq * target_freq.conj()
     cross_correlation = np.fft.ifftn(image_product)
@@ -204,6 +209,36 @@ def rigid_template(video, max_shifts, num_iter=1, template=None, add_to_movie=No
         new_temp[np.isnan(new_temp)] = np.nanmin(new_temp)
         new_templ = np.nanmedian(np.stack([new_temp]), 0)
     return new_templ, np.array(shifts, dtype=np.float64), mc
+
+
+def register_translation(src_image, target_image, upsample_factor=1, shifts_lb=None, shifts_ub=None, max_shifts=(10, 10)):
+    """The 2-D register_translation :801-1024 (space='real'): the same algorithm on two axes -- window, argmax, upsampled
+    DFT -- so it is evaluated here as the 3-D restatement on an (X, Y, 1) array: a third axis of one voxel leaves every
+    window of :727-747 empty and its shift zero (:789-791).  Differences kept: the 2-D function takes the images to
+    complex128 directly (no complex64 step, :919-924); it calls cv2.dft where this uses numpy.fft (cv2 is absent; the forward
+    scale factor of cv2.DFT_SCALE does not move a maximum)."""
+    ext = lambda v, z: None if v is None else np.array(list(v) + [z])      # (z window [-1, 1): zeroes nothing of one slice)
+    s = register_translation_3d(np.asarray(src_image)[:, :, None], np.asarray(target_image)[:, :, None], upsample_factor,
+                                ext(shifts_lb, -1), ext(shifts_ub, 1), tuple(max_shifts) + (0,), to_complex64=False)
+    return s[:2]
+
+
+def tile_shifts_2d(img, template, strides, overlaps, max_shifts, upsample_factor_fft=10, max_deviation_rigid=3, add_to_movie=0.0):
+    """tile_and_correct :1272-1418 up to its `total_shifts` (shifts_opencv=True branch): (rigid (2,), total_shifts (NP,2) =
+    (-x, -y) :1415-1416) over the patches of sliding_window :1160-1188."""
+    img = np.asarray(img, dtype=np.float64) + add_to_movie
+    template = np.asarray(template, dtype=np.float64) + add_to_movie
+    rigid = register_translation(img, template, upsample_factor_fft, max_shifts=max_shifts)
+    lb = np.ceil(np.subtract(rigid, max_deviation_rigid)).astype(int)
+    ub = np.floor(np.add(rigid, max_deviation_rigid)).astype(int)
+    w = np.add(overlaps, strides)
+    out = []
+    for x in patch_starts(img.shape[0], overlaps[0], strides[0]):
+        for y in patch_starts(img.shape[1], overlaps[1], strides[1]):
+            sh = register_translation(img[x:x + w[0], y:y + w[1]], template[x:x + w[0], y:y + w[1]], upsample_factor_fft,
+                                      shifts_lb=lb, shifts_ub=ub, max_shifts=max_shifts)
+            out.append((-sh[0], -sh[1]))
+    return rigid, np.array(out, dtype=np.float64)
 
 
 def tile_shifts_3d(img, template, strides, overlaps, max_shifts, upsample_factor_fft=10, max_deviation_rigid=3,

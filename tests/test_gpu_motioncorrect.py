@@ -137,7 +137,7 @@ def test_motioncorrect_front_end_and_apply_shifts_points(ops, MO):
     dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=torch.from_numpy(P_T[:, :, 0]).float())
     assert tuple(dn.fp.A.shape) == (*sz, K)
     with pytest.raises(NotImplementedError):
-        MotionCorrect(video, is3D=False)
+        MotionCorrect(video[..., 0], is3D=False).apply_shifts_points(video, points)
 
 
 @pytest.mark.parametrize("sz,max_shifts", [([48, 40, 2], (5, 5, 1)), ([40, 36, 5], (6, 4, 2)), ([64, 64, 1], (6, 6, 0))])
@@ -230,3 +230,22 @@ def test_rigid_correction_border_modes(ops, MO, border):
         checked += 1
     assert checked >= 3
     assert int(tcount.min()) == T
+
+
+def test_two_dimensional_video(ops, MO):
+    """is3D=False: a (T, X, Y) video through register_translation / tile_and_correct (reference :801-1024, :1272-1418) =
+    the same kernels on one slice; x_shifts_els / y_shifts_els against oracle.tile_shifts_2d."""
+    from dnmf_amd.Demix.MotionCorrect import MotionCorrect
+    sz, T = [64, 56, 1], 5
+    video, template, _, _ = synthetic_video(sz, T, 40, seed=31)
+    video2, template2 = video[..., 0], template[..., 0]
+    mc = MotionCorrect(video2, max_shifts=(6, 6), strides=(24, 20), overlaps=(8, 8), max_deviation_rigid=3, is3D=False, pw_rigid=True)
+    mc.motion_correct(template=template2)
+    assert not hasattr(mc, "z_shifts_els") and len(mc.x_shifts_els) == T and len(mc.coord_shifts_els[0][0]) == 2
+    ref = np.array([MO.tile_shifts_2d(img, template2, (24, 20), (8, 8), (6, 6), 10, 3, -float(video2.min()))[1] for img in video2])
+    got = np.stack([np.stack(mc.x_shifts_els), np.stack(mc.y_shifts_els)], 2)
+    bins = np.abs(got - ref) * 10
+    assert bins.max() <= 1.0 + 1e-3 and (bins < 1e-3).mean() >= 0.95
+    assert np.abs(ref).max() > 1.0 and tuple(mc.total_template_els.shape) == (64, 56)
+    with pytest.raises(NotImplementedError):
+        mc.motion_correct_rigid()

@@ -113,3 +113,19 @@ def test_border_modes_of_the_oracle():
     np.testing.assert_allclose(cp[6, 0, 2], plain[6, 2, 2])
     np.testing.assert_allclose(cp[6, 5, 0], plain[6, 5, 1])
     np.testing.assert_allclose(cp[-1, 0, 0], plain[-4, 2, 1])       # a corner: every index clamped
+
+
+def test_two_dimensional_functions_of_the_oracle():
+    from oracle import motion_oracle as MO
+    tm = smooth_volume((48, 40, 1), 5)[:, :, 0]
+    img = fourier_shift(tm[:, :, None], (2.3, -1.6, 0.0))[:, :, 0]
+    np.testing.assert_allclose(MO.register_translation(img, tm, 10, max_shifts=(6, 6)), [2.3, -1.6], atol=1e-6)
+    rigid, ts = MO.tile_shifts_2d(img, tm, (16, 12), (8, 8), (5, 5))
+    np.testing.assert_allclose(rigid, [2.3, -1.6], atol=1e-6)
+    assert ts.shape == (len(MO.patch_starts(48, 8, 16)) * len(MO.patch_starts(40, 8, 12)), 2)
+    # (-x, -y); a small patch of a non-periodic field under-estimates its shift (circular correlation)
+    assert -3.0 < np.median(ts[:, 0]) < -0.3 and 0.3 < np.median(ts[:, 1]) < 2.2
+    # the same numbers as the 3-D functions on one slice
+    r3, t3 = MO.tile_shifts_3d(img[:, :, None], tm[:, :, None], (16, 12, 1), (8, 8, 0), (5, 5, 0))
+    np.testing.assert_allclose(ts, t3[:, :2], atol=0.1 + 1e-9)      # (complex64 rounding in the 3-D function only: a bin at most)
+    assert (np.abs(ts - t3[:, :2]) < 1e-9).mean() > 0.9
