@@ -150,6 +150,104 @@ __global__ __launch_bounds__(256) void mc_axis_kernel(McAxis a) {
     }
 }
 
+// The same primitive on the matrix pipe (round 3): out = W in with W[r][j] = exp(sign 2 pi i f_j pos_r / (n uf)) generated on
+// the fly -- a complex GEMM as four f32 MFMAs (v_mfma_f32_32x32x2_f32: exact f32 products, fmaf accumulation) per step of two
+// input rows j:  Re += Wre.vre - Wim.vim,  Im += Wre.vim + Wim.vre.  A wave owns a tile of 32 output rows x 32 columns (two
+// 16-register accumulators); per step a lane supplies ONE entry of W (row l & 31, j = j0 + (l >> 5): one table lookup, its
+// integer phase advanced by two frequencies) and ONE input value (j = j0 + (l >> 5), column l & 31: one load) -- the table
+// lookups the vector kernel made per (row, j, column) are made per (row, j) here, and the multiply-adds leave the vector ALU.
+// A block is 2 x 2 waves: 64 rows x 64 columns.  Same arguments, same results up to the order of the sums over j.
+typedef float mc_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mc_axis_mfma_kernel(McAxis a) {
+    extern __shared__ float2 s_root[];      // exp(2 pi i k / D), k = 0 .. D-1
+    const int item = blockIdx.z;
+    const int D = a.n * a.uf;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float sn, cs;
+        sincospif(2.0f * (float)k / (float)D, &sn, &cs);
+        s_root[k] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const long ncol = (long)a.outer * a.inner;
+    const long col = (long)blockIdx.x * 64 + (wave & 1) * 32 + l31;      // the column this lane loads AND stores
+    const bool live = col < ncol;
+    const long colc = live ? col : ncol - 1;
+    const int o = (int)(colc / a.inner), i = (int)(colc - (long)o * a.inner);
+    const int row0 = blockIdx.y * 64 + (wave >> 1) * 32;                  // first output row of the wave's tile
+    if (row0 >= a.m) return;                                              // (whole wave; no barrier below)
+    // phase bookkeeping of this lane's W row r = row0 + l31: idx = (sign pos f_j) mod D for j = j0 + h
+    const int *pos = a.pos + (long)item * a.pos_item_stride + a.pos_off;
+    const int half = (a.n + 1) / 2;
+    const int r = row0 + l31;
+    bool rowok = r < a.m;
+    long p = rowok ? (long)pos[r] : 0;
+    if (rowok && pos[r] == INT_MIN) rowok = false, p = 0;                 // an unused slot of a window
+    p *= a.sign;
+    long s1 = p % D;
+    if (s1 < 0) s1 += D;
+    long s2 = (p * (1 - (long)a.n)) % D;
+    if (s2 < 0) s2 += D;
+    const int step = (int)s1, wrap = (int)s2;
+    int idx = h == 0 ? 0 : (1 == half ? wrap : step);                     // j = h
+    idx -= idx >= D ? D : 0;
+    // where this lane's input column starts
+    const float *fsrc = nullptr;
+    const float2 *csrc = nullptr, *osrc = nullptr;
+    long stride = a.inner;
+    const int box = item % a.bx.nbox;
+    if (a.mode == 0) {
+        const int frame = a.first_frame + item / a.bx.nbox;
+        const int x = o / a.bx.n[1], y = o - x * a.bx.n[1];
+        const int *st = a.bx.start + 3 * box;
+        fsrc = a.frames + (long)(a.frame_ids ? a.frame_ids[frame] : frame) * a.ldf + ((long)(st[0] + x) * a.Y + (st[1] + y)) * a.Z + st[2];
+        stride = 1;
+    } else {
+        const long base = ((long)o * a.n) * a.inner + i;
+        csrc = a.in + (long)item * a.outer * a.n * a.inner + base;
+        if (a.mode == 2) osrc = a.other + (long)box * a.outer * a.n * a.inner + base;
+    }
+    mc_f32x16 are, aim;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) are[q] = 0.0f, aim[q] = 0.0f;
+    for (int j0 = 0; j0 < a.n; j0 += 2) {
+        const int j = j0 + h;
+        const bool jin = j < a.n;
+        const int jc = jin ? j : a.n - 1;
+        float2 v;
+        if (a.mode == 0) {
+            v = make_float2(fsrc[(long)jc * stride] + a.add, 0.0f);
+        } else {
+            v = csrc[(long)jc * stride];
+            if (a.mode == 2) {
+                const float2 w = osrc[(long)jc * stride];   // v conj(w)
+                v = make_float2(fmaf(v.x, w.x, v.y * w.y), fmaf(v.y, w.x, -v.x * w.y));
+            }
+        }
+        if (!jin) v = make_float2(0.0f, 0.0f);
+        float2 t = s_root[idx];
+        if (!rowok) t = make_float2(0.0f, 0.0f);
+        are = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, v.x, are, 0, 0, 0);
+        are = __builtin_amdgcn_mfma_f32_32x32x2f32(-t.y, v.y, are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x2f32(t.x, v.y, aim, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x2f32(t.y, v.x, aim, 0, 0, 0);
+        // two frequencies on: j -> j + 1 -> j + 2 (the step from half - 1 to half is the wrap)
+        idx += (j + 1 == half) ? wrap : step;
+        idx -= idx >= D ? D : 0;
+        idx += (j + 2 == half) ? wrap : step;
+        idx -= idx >= D ? D : 0;
+    }
+    if (!live) return;
+    // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float2 *dst = a.out + (long)item * a.outer * a.m * a.inner + ((long)o * a.m) * a.inner + i;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int rr = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (rr < a.m) dst[(long)rr * a.inner] = make_float2(are[q] * a.scale, aim[q] * a.scale);
+    }
+}
+
 __global__ void mc_fill_kernel(float *p, int n, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -299,8 +397,18 @@ struct McPlan {
     int items;
 };
 
+static bool mc_use_mfma() {
+    const char *e = getenv("DNMF_K8_VALU");     // 1: the vector-ALU kernel (the checker of the MFMA one); read at every call
+    return !(e && e[0] == '1');
+}
+
 static void mc_launch_axis(McAxis a, int items, size_t maxD_bytes, hipStream_t st) {
     const long ncol = (long)a.outer * a.inner;
+    if (mc_use_mfma()) {
+        dim3 grid((unsigned)((ncol + 63) / 64), (unsigned)((a.m + 63) / 64), (unsigned)items);
+        hipLaunchKernelGGL(mc_axis_mfma_kernel, grid, dim3(256), (size_t)a.n * a.uf * sizeof(float2), st, a);
+        return;
+    }
     dim3 grid((unsigned)((ncol + MC_TC - 1) / MC_TC), (unsigned)((a.m + MC_RTILE - 1) / MC_RTILE), (unsigned)items);
     hipLaunchKernelGGL(mc_axis_kernel, grid, dim3(256), (size_t)a.n * a.uf * sizeof(float2), st, a);
 }

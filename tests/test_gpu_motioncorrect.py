@@ -249,3 +249,25 @@ def test_two_dimensional_video(ops, MO):
     assert np.abs(ref).max() > 1.0 and tuple(mc.total_template_els.shape) == (64, 56)
     with pytest.raises(NotImplementedError):
         mc.motion_correct_rigid()
+
+
+def test_matrix_pipe_kernel_equals_the_vector_kernel(ops, monkeypatch):
+    """K8's axis transform runs as f32 MFMAs (mc_axis_mfma_kernel); DNMF_K8_VALU=1 selects the vector-ALU kernel it replaced.
+    Same shifts (a bin apart at most, 98 % identical: the sums over j run in a different order) and the same moved frames to
+    1e-5 of the range, on a volume with odd sizes, a patch grid and every pass (forward, windowed inverse, upsampled inverse,
+    the full inverse on a shifted grid)."""
+    sz, T = [72, 50, 3], 6
+    video, template, _, _ = synthetic_video(sz, T, 40, seed=12)
+    frames, tm = torch.from_numpy(video.reshape(T, -1)).cuda(), torch.from_numpy(template).cuda()
+    add = -float(video.min())
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DNMF_K8_VALU", mode)
+        rigid, patch = ops.register_patches(frames, tm, sz, (20, 14, 2), (10, 8, 1), (6, 5, 1), 3, 10, add)
+        r2, out, _, _ = ops.rigid_correct(frames, tm, sz, (6, 5, 1), 10, add, False, want_frames=True)
+        res[mode] = (rigid.cpu().numpy(), patch.cpu().numpy(), r2.cpu().numpy(), out.cpu().numpy())
+    for a, b in zip(res["0"][:3], res["1"][:3]):
+        assert np.abs(a - b).max() <= 0.1 + 1e-4 and (np.abs(a - b) < 1e-4).mean() >= 0.98
+    same = np.abs(res["0"][2] - res["1"][2]).max(1) < 1e-4
+    scale = float(video.max() - video.min())
+    np.testing.assert_allclose(res["0"][3][same], res["1"][3][same], rtol=0, atol=1e-5 * scale)
