@@ -227,6 +227,57 @@ class HostVideo(torch.utils.data.Dataset):
         return sample, idx
 
 
+def position_initialiser_extra(size, Z=2, T=256):
+    """K8: the registration behind MotionCorrect on a size x size x Z video of T frames -- the rigid pass
+    (dnmf_rigid_correct: shifts, every frame moved through its spectrum) and the piecewise pass (dnmf_register_patches: 5 x 5
+    patches) -- with the roofline of the axis transform: f32 MFMAs.  The flops counted are those of the full-length
+    transforms only (forward transforms of the volume and of the patches, the full inverse of the rigid pass: 8 flops per
+    complex multiply-add, N (n0 + n1 + n2) of them per box); the windowed and upsampled inverses come on top, uncounted."""
+    import time
+    from dnmf_amd import ops
+    sz = [size, size, Z]
+    P = size * size * Z
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.rand(T, P, device="cuda", generator=gen)
+    tmpl = frames.mean(0)
+    stride, overlap = (3 * size) // 16, size // 16
+    st, ov, ms = (stride, stride, 1), (overlap, overlap, Z - 1), (6, 6, 1 if Z > 1 else 0)
+    dims, _ = ops.patch_grid(sz, st, ov)
+    w = [a + b for a, b in zip(st, ov)]
+    NP = int(dims[0] * dims[1] * dims[2])
+    fwd_full = 8.0 * P * (size + size + Z)
+    fwd_patch = 8.0 * NP * w[0] * w[1] * w[2] * (w[0] + w[1] + w[2])
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    t_pw = timed(lambda: ops.register_patches(frames, tmpl, sz, st, ov, ms, 3, 10, 0.0))
+    t_rg = timed(lambda: ops.rigid_correct(frames, tmpl, sz, ms, 10, 0.0, True))
+    peak = 157.3
+    out = {"workload": f"{size}x{size}x{Z}, {T} frames, {NP} patches of {w[0]}x{w[1]}x{w[2]}, max_shifts {ms}, upsample factor 10",
+           "register_patches_frames_per_s": T / t_pw, "rigid_correct_frames_per_s": T / t_rg,
+           "rooflines": [
+               {"kernel": "mc_axis_mfma_kernel in dnmf_register_patches (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                "achieved": T * (fwd_full + fwd_patch) / t_pw / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": T * (fwd_full + fwd_patch) / t_pw / 1e12 / peak, "traffic": None,
+                "count": "forward transforms of the volume and of every patch; wall time of the whole call"},
+               {"kernel": "mc_axis_mfma_kernel in dnmf_rigid_correct", "bound": "mfma", "achieved": T * 2 * fwd_full / t_rg / 1e12,
+                "peak": peak, "unit": "TFLOP/s", "frac": T * 2 * fwd_full / t_rg / 1e12 / peak, "traffic": None,
+                "count": "forward transform of the volume + the full inverse on the shifted grid; wall time of the whole call"}],
+           "note": "parity unpinned (DESIGN 2: the reference module cannot be imported here and holds no fixture)"}
+    del frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def displaced_beta(T, sz, device, seed=7):
     """(10,3,T) warps about a voxel off the identity: shifts of +-1 px, linear terms of +-0.2 %, quadratic terms that move
     the far corner by ~1 px, z row left at the identity; smooth in t (random walk of period ~200 frames).  (Warps several
@@ -625,6 +676,7 @@ def main():
                                     "are drawn")
         del r5
         torch.cuda.empty_cache()
+        extras["position_initialiser"] = position_initialiser_extra(size)
         extras["stock_dataloader"] = dict(dl, note="torch.utils.data.DataLoader(batch 4, shuffle, num_workers=0) over a host "
                                                    "copy of the video, as demo.py:33-35; every sweep serves the video twice "
                                                    "from the host (update_motion, update_footprints)")
