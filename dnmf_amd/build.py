@@ -28,6 +28,7 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dnmf_hip.h")]
+    deps.append(os.path.abspath(__file__))      # the per-file flags live here
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -40,6 +41,9 @@ PER_FILE_FLAGS = {
     # K2: the SLP vectoriser's packed fp32 operations issue no faster than two scalar ones and cost register shuffles
     # (512x512x2x4000: 6.55 ms against 6.93; Z == 1 unchanged)
     "warp_recon_grad.hip": ["-fno-slp-vectorize"],
+    # K7: the same -- the packed operations come with s_nop wait states between dependent ones
+    # (512x512 x 4000 frames: 3.65 ms against 4.14; 512x512x2 x 1000: 5.56 against 7.01)
+    "image_iwarp.hip": ["-fno-slp-vectorize"],
     # K3n for Z >= 2: packed operations want their operands in register pairs -- 200 registers instead of 150, spills
     # (512x512x2x4000: 19.9 ms against 6.6); the Z == 1 instantiations (warp_gram_lists.hip) keep the vectoriser
     "warp_gram_lists_z.hip": ["-fno-slp-vectorize"],

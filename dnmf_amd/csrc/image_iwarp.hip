@@ -316,6 +316,9 @@ __device__ __forceinline__ float iw_sqrt_up(float x) { return fmaf(__builtin_amd
 #define DNMF_IW_ROWS 16   // (8: 4.33 ms per 4000 frames of 512x512, 16: 4.22, 32: 4.12 -- and fewer blocks for small volumes)
 #endif
 constexpr int IW_ROWS = DNMF_IW_ROWS;
+#ifndef DNMF_IW_LAG_Z
+#define DNMF_IW_LAG_Z 1   // Z > 1 too: one evaluation of the continuous map per row (see the row loop)
+#endif
 #ifndef DNMF_IW_SHARE
 #define DNMF_IW_SHARE 8
 #endif
@@ -387,10 +390,13 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
         // the clamped point (two evaluations of s per row).  Z == 1: every other row starts from the last row's clamped point
         // vc moved by ITS residual and by one row -- one evaluation of s per row: the residual measured here both certifies
         // this row (rho) and corrects the next one; the one-row lag leaves |J - I| of a voxel in rho (0.004 for the warps of a
-        // fit), which the radius absorbs: 5.56 -> 5.37 ms per 4000 frames.  (For Z > 1 the same change took the kernel from
-        // 162 to 179 registers, three waves per SIMD to two: 8.2 -> 10.2 ms per 1000 frames of 512x512x2; not used there.)
+        // fit), which the radius absorbs: 5.56 -> 5.37 ms per 4000 frames.  (For Z > 1 the same change first took the kernel
+        // from 162 to 179 registers, three waves per SIMD to two; compiled without the SLP vectoriser -- build.py -- the kernel
+        // needs 120 and the walk is the same at every depth: 5.45 -> 5.23 ms per 1000 frames of 512x512x2.  DNMF_IW_LAG_Z=0
+        // keeps the two-evaluation walk for Z > 1.)
         float vc[3] = {0.0f, 0.0f, 0.0f};
-        if (HASZ || gx == x_first) {
+        constexpr bool TWO_EVALS = HASZ && !DNMF_IW_LAG_Z;
+        if (TWO_EVALS || gx == x_first) {
             const int steps = gx == x_first ? 2 : 1;
             for (int it = 0; it < steps; ++it) {
                 residual();
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
 #pragma unroll
             for (int d = 0; d < ND; ++d) vc[d] = __builtin_amdgcn_fmed3f(v[d], 0.0f, (float)(S[d] - 1)), v[d] = vc[d];   // (one instruction)
             residual();   // at the clamped point (the stretch bound holds between points of the volume)
-            if (HASZ) {
+            if (TWO_EVALS) {
                 v[0] = keep[0] + k[0], v[1] = keep[1], v[2] = keep[2];    // the next row starts here
             } else {
 #pragma unroll
