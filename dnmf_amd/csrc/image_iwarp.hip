@@ -386,9 +386,9 @@ __global__ __launch_bounds__(256) void image_iwarp_rows_kernel(const float *__re
             for (int d = 0; d < ND; ++d) res[d] = gf[d] - poly_a<HASZ>(b2, d, mo) * hk[d];
         };
         // The estimate of the pre-image: fixed-point steps v <- v + (g - s(v)) k, two from g k for the first row of the walk.
-        // Z > 1: every other row takes one step from the last row's estimate moved by a row, then measures what is left at
-        // the clamped point (two evaluations of s per row).  Z == 1: every other row starts from the last row's clamped point
-        // vc moved by ITS residual and by one row -- one evaluation of s per row: the residual measured here both certifies
+        // The two-evaluation walk (round 3's first form): every other row takes one step from the last row's estimate moved by
+        // a row, then measures what is left at the clamped point.  The walk used now: every other row starts from the last row's
+        // clamped point vc moved by ITS residual and by one row -- one evaluation of s per row: the residual measured here both certifies
         // this row (rho) and corrects the next one; the one-row lag leaves |J - I| of a voxel in rho (0.004 for the warps of a
         // fit), which the radius absorbs: 5.56 -> 5.37 ms per 4000 frames.  (For Z > 1 the same change first took the kernel
         // from 162 to 179 registers, three waves per SIMD to two; compiled without the SLP vectoriser -- build.py -- the kernel
