@@ -74,6 +74,9 @@ typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef DNMF_K3N_DMA
 #define DNMF_K3N_DMA 1   // 1: the regions of a list go from global memory straight into LDS (global_load_lds), all of them
 #endif                   // requested ahead of the tile's coordinate arithmetic, through no registers (round 3: 3.14 -> 2.91 ms)
+#ifndef DNMF_K3N_LATE_FRAMES
+#define DNMF_K3N_LATE_FRAMES 1   // the wait in front of the staged taps covers the regions only, not the frame values
+#endif
 #ifndef DNMF_K3N_DMA2
 #define DNMF_K3N_DMA2 1  // the same for the two groups of a long list (second launch)
 #endif
@@ -722,7 +725,18 @@ __global__ __launch_bounds__(256, (ZM == 1 ? DNMF_K3N_WAVES : (ZM == 2 ? (PASS =
                 constexpr int N = decltype(nn)::value;
                 float a[N][LISTS_VPL];
                 if (staged && DMA) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the regions (and the frame values) have landed
+                    // The regions have landed: they were requested BEFORE the tile's LISTS_VPL frame values (one load each, issued
+                    // by taps() of a full tile, none in between: sched_barrier after the requests, this statement a compiler
+                    // barrier), and vector memory returns in order -- "at most LISTS_VPL outstanding" = every region is in LDS,
+                    // while the frame values (from HBM, the longest latency of the tile) may still be on their way: they are not
+                    // needed until the sums after the taps, where the compiler places its own wait.  (2.98 -> 2.92 ms per 4000
+                    // frames of 512x512, K = 100; nothing at Z = 2.)
+#if DNMF_K3N_LATE_FRAMES
+                    if (full)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LISTS_VPL) : "memory");
+                    else
+#endif
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         eval_staged(i, a[i]);
