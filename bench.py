@@ -143,7 +143,8 @@ def other_kernels(evs, P, K, T_loc, tjson, key, Pp):
     rl = evs("recon_image_lists")
     if rl:
         ms = 1e3 * sum(rl) / len(rl)
-        b = 4.0 * P * T_loc   # the reconstruction image, written once (algorithmic; the halo layout adds Pp/P - 1)
+        b = 4.0 * P * T_loc   # the reconstruction image, written once (algorithmic; the halo layout adds Pp/P - 1; in steady
+        #                       state the tiles without a neuron -- ~10 % here -- are not rewritten, see `traffic`)
         out.append({"kernel": "recon_lists_kernel (reconstruction image from neuron lists)", "bound": "hbm",
                     "launch_ms": ms, "bytes_per_launch": b, "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,

@@ -145,14 +145,22 @@ class ExponentialFP(nn.Module):
         sub = self.A.reshape(self.P, self.K)[:, torch.as_tensor(cols, device=self.A.device)].contiguous()
         return ops.pack_footprints(sub)
 
-    def recon_image(self, C, times, out=None):
+    def recon_image(self, C, times, out=None, zero_state=None):
         """S[b] = A . C[:, times[b]] as (B, >= ops.halo_voxels(sz)) rows in the halo layout K2 gathers from: from the
         neuron lists when the footprints are compact (``use_lists``), else ``dnmf_recon_image`` (fp32 MFMA), by groups
         of 112 neurons when K > 127."""
         if self.use_lists and self.K <= 256:
             ly = self.packed_lists()
             if ly["boxfrac"] < LISTS_BOXFRAC_LIMIT:
-                return ops.recon_image_lists(ly, self.K, self.sz_list, C, times, out=out)
+                # zero_state: a one-entry list the owner of a persistent ``out`` keeps -- the layout whose empty tiles are
+                # known to hold zeros in these rows (written by a call without skipping); None after any other writer
+                skip = zero_state is not None and zero_state[0] is ly
+                res = ops.recon_image_lists(ly, self.K, self.sz_list, C, times, out=out, skip_empty=skip)
+                if zero_state is not None:
+                    zero_state[0] = ly
+                return res
+        if zero_state is not None:
+            zero_state[0] = None
         if self.K <= 127:
             return ops.recon_image(self.packed_footprints(), self.K, self.sz_list, C, times, out=out)
         for n, s0 in enumerate(range(0, self.K, 112)):
@@ -279,6 +287,7 @@ class DeformableNMF:
         self._ws_k2 = None
         self._ws_k3 = None
         self._S_bufs = None
+        self._S_zero = None
         self._gram_nbr = None   # (K,NN) columns of the last Gram matrices that can be non-zero, when K3n made them
         # update_motion evaluates a whole epoch per launch when the caller's optimiser is a plain
         # torch.optim.Adam on [fp.beta] and the loader is a ResidentLoader (same result, see _motion_epoch)
@@ -643,10 +652,16 @@ class DeformableNMF:
         # re-map its large blocks (tens of milliseconds every few sweeps)
         if self._S_bufs is None or len(self._S_bufs) != len(chans) or self._S_bufs[0].shape != (fp0.T, lds):
             self._S_bufs = [torch.empty((fp0.T, lds), dtype=torch.float32, device=device) for _ in chans]
+            self._S_zero = [[None] for _ in chans]
         out = []
-        for (fp, _), S in zip(chans, self._S_bufs):
+        for (fp, _), S, zs in zip(chans, self._S_bufs, self._S_zero):
+            # every row is rewritten on every call; tiles no neuron reaches were zeroed by the first call with these
+            # footprints and are skipped from then on (a third of the tiles -- and of the stores -- at 512x512, K = 100)
+            was = zs[0]
             for s in range(0, fp.T, 32768):
-                fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768])
+                state = [was]
+                fp.recon_image(C, all_t[s:s + 32768], out=S[s:s + 32768], zero_state=state)
+            zs[0] = state[0]
             out.append(S)
         return out
 

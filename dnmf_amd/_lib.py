@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DNMF_LIB selects another build of the library (kernel-variant timing, ablations); the product default is in-tree
 LIB_PATH = os.environ.get("DNMF_LIB") or os.path.join(_HERE, "libdnmf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _l, _sz, _d = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_double
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "dnmf_warp_gram_rhs_lists": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp, _vp, _vp,
                                       _vp, _sz, _vp, _vp]),
     "dnmf_recon_image_lists": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
+    "dnmf_recon_image_lists_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp, _l, _i, _vp]),
     "dnmf_motion_grad_lists_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dnmf_motion_grad_lists": (_i, [_vp, _vp, _i, _vp, _l, _vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i,
                                     _vp, _sz, _vp]),

@@ -22,7 +22,7 @@ template <int NW>
 __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restrict__ At, const int *__restrict__ bbox,
                                                           int K, Volume vol, HaloLayout hl, const float *__restrict__ C, long ldc,
                                                           const int *__restrict__ times, int B, float *__restrict__ S,
-                                                          long lds, int nu, int frames_per_wave) {
+                                                          long lds, int nu, int frames_per_wave, int skip_empty) {
     __shared__ int s_list[4][64 * NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void recon_lists_kernel(const float *__restric
     float *__restrict__ out = S + voxel;
     const rl_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (n == 0) {
+        // skip_empty: the caller vouches that this tile of every row of S already holds zeros (an earlier call with the same
+        // boxes wrote them): about a third of the tiles at 512x512, K = 100 -- of a kernel bound by its stores
+        if (skip_empty) return;
         for (int b = b0; b < b1; ++b)
             if (in) *reinterpret_cast<rl_f4 *>(out + (long)b * lds) = zero4;
         return;
@@ -108,6 +111,11 @@ extern "C" {
 
 int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
                            const int *times, int B, float *S, long lds, dnmf_stream_t stream) {
+    return dnmf_recon_image_lists_ex(At, bbox, K, X, Y, Z, C, ldc, times, B, S, lds, 0, stream);
+}
+
+int dnmf_recon_image_lists_ex(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
+                              const int *times, int B, float *S, long lds, int skip_empty, dnmf_stream_t stream) {
     using namespace dnmf;
     DNMF_REQUIRE(At && bbox && C && S, DNMF_E_NULL, "dnmf_recon_image_lists: NULL buffer");
     DNMF_REQUIRE(X > 0 && Y > 0 && Z > 0 && K > 0 && B > 0, DNMF_E_SHAPE, "dnmf_recon_image_lists: X=%d Y=%d Z=%d K=%d B=%d",
@@ -130,11 +138,11 @@ int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ntile, (unsigned)ny);
     if (K <= 64)
-        hipLaunchKernelGGL(recon_lists_kernel<1>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<1>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw, skip_empty);
     else if (K <= 128)
-        hipLaunchKernelGGL(recon_lists_kernel<2>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<2>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw, skip_empty);
     else
-        hipLaunchKernelGGL(recon_lists_kernel<4>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw);
+        hipLaunchKernelGGL(recon_lists_kernel<4>, grid, dim3(256), 0, st, At, bbox, K, vol, hl, C, ldc, times, B, S, lds, nu, fpw, skip_empty);
     return check_launch("dnmf_recon_image_lists");
 }
 

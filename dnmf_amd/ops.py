@@ -122,8 +122,11 @@ def recon_image(Apk: torch.Tensor, K: int, sz, C: torch.Tensor, times, out: torc
     return out
 
 
-def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Tensor | None = None) -> torch.Tensor:
-    """S as ``recon_image`` from the K3n layout (``pack_footprints_lists``): compact footprints, static tile lists."""
+def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Tensor | None = None,
+                      skip_empty: bool = False) -> torch.Tensor:
+    """S as ``recon_image`` from the K3n layout (``pack_footprints_lists``): compact footprints, static tile lists.
+    ``skip_empty``: tiles without a neuron are left alone -- only for an ``out`` whose rows an earlier call with the same
+    layout and ``skip_empty=False`` has written (they hold zeros there)."""
     X, Y, Z = (int(s) for s in sz)
     _f32(C, "C")
     tt = _i32(times, C.device)
@@ -134,10 +137,10 @@ def recon_image_lists(layout, K: int, sz, C: torch.Tensor, times, out: torch.Ten
     if out.shape[0] < B or out.stride(0) < lds or out.stride(1) != 1:
         raise ValueError("recon_image_lists: out must be (>=B, ld) with ld >= halo_voxels(sz)")
     with _timed("recon_image_lists"):
-        rc = _lib.load().dnmf_recon_image_lists(layout["At"].data_ptr(), layout["bbox"].data_ptr(), K, X, Y, Z,
-                                                C.data_ptr(), C.stride(0), tt.data_ptr(), B, out.data_ptr(),
-                                                out.stride(0), _stream())
-    _lib.check(rc, "dnmf_recon_image_lists")
+        rc = _lib.load().dnmf_recon_image_lists_ex(layout["At"].data_ptr(), layout["bbox"].data_ptr(), K, X, Y, Z,
+                                                   C.data_ptr(), C.stride(0), tt.data_ptr(), B, out.data_ptr(),
+                                                   out.stride(0), 1 if skip_empty else 0, _stream())
+    _lib.check(rc, "dnmf_recon_image_lists_ex")
     return out
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DNMF_ABI_VERSION 5
+#define DNMF_ABI_VERSION 6
 
 #define DNMF_OK 0
 #define DNMF_E_NULL (-1)      /* required pointer is NULL */
@@ -198,6 +198,11 @@ int dnmf_warp_gram_rhs_lists(const float *At, const int *bbox, const int *pair_s
  * floats (dnmf_halo_voxels is a multiple of 32). */
 int dnmf_recon_image_lists(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
                            const int *times, int B, float *S, long lds, dnmf_stream_t stream);
+/* The same with skip_empty != 0: tiles no neuron's box meets are left alone instead of being zeroed -- for a caller that
+ * keeps S between calls and knows those tiles hold zeros already (an earlier call with skip_empty == 0 and the same bbox on
+ * the same rows of S wrote them). */
+int dnmf_recon_image_lists_ex(const float *At, const int *bbox, int K, int X, int Y, int Z, const float *C, long ldc,
+                              const int *times, int B, float *S, long lds, int skip_empty, dnmf_stream_t stream);
 
 /* One group of mini-batches of the fused motion epoch with the reconstruction images kept in the last-level cache:
  * dnmf_recon_image_lists and dnmf_warp_recon_grad (its frames / frame_ids / times / norm_frames / grad / frame_loss / reg

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_padding(lib):
-    assert lib.dnmf_version() == 5
+    assert lib.dnmf_version() == 6
     assert [lib.dnmf_padded_k(k) for k in (0, 1, 10, 15, 16, 50, 100, 111, 112, 200)] == \
         [0, 16, 16, 16, 32, 64, 112, 112, 128, 208]
 

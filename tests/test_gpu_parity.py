@@ -1121,3 +1121,38 @@ def test_resident_dataset_and_loader(M):
     A_t, Y_i, Y = dn.update_footprints(ds.loader(4), 4, sz, gamma_c=0, iter_c=5)
     assert A_t.shape == (40, 32, 2, K, T) and np.isfinite(dn.C.cpu().numpy()).all()
     np.testing.assert_allclose(Y, np.maximum(ds.video.double().cpu().numpy(), 0), rtol=0, atol=0)
+
+
+def test_reconstruction_cache_skips_tiles_without_neurons(M):
+    """update_motion keeps its reconstruction images between calls; tiles of the image that no neuron's box reaches are
+    zeroed by the first call and left alone afterwards (dnmf_recon_image_lists_ex, skip_empty).  The images must equal a
+    fresh reconstruction bit for bit on every call -- also after the traces change, and after the FOOTPRINTS change (new
+    boxes: the next call writes everything again, including zeros where a neuron used to be)."""
+    from dnmf_amd import ops
+    torch.manual_seed(4)
+    sz, K, T = [96, 80, 1], 12, 9
+    pos = torch.rand(K, 3) * torch.tensor([96.0, 80.0, 0.0])
+    dn = M.DeformableNMF(torch.tensor(sz), K, T, positions=pos)
+    dn.C = torch.rand(K, T, device="cuda") + 0.1
+    all_t = torch.arange(T, dtype=torch.int32, device="cuda")
+
+    def fresh():
+        return dn.fp.recon_image(dn.C, all_t).clone()
+
+    S1 = dn._recon_cache()[0]
+    assert torch.equal(S1, fresh())
+    assert float((S1 == 0).float().mean()) > 0.1          # there are empty tiles to skip
+    dn.C = torch.rand(K, T, device="cuda") + 0.1
+    ly = dn.fp.packed_lists()
+    S2 = dn._recon_cache()[0]
+    assert S2.data_ptr() == S1.data_ptr() and dn._S_zero[0][0] is ly
+    assert torch.equal(S2, fresh())
+    # move a neuron: footprints change in place -> new lists -> a full write (the old footprint's voxels must become zero)
+    with torch.no_grad():
+        A = dn.fp.A
+        A[..., 0] = torch.roll(A[..., 0], shifts=(17, -11), dims=(0, 1))
+    assert dn.fp.packed_lists() is not ly
+    S3 = dn._recon_cache()[0]
+    assert torch.equal(S3, fresh())
+    S4 = dn._recon_cache()[0]
+    assert torch.equal(S4, fresh())
