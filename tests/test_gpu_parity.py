@@ -1156,3 +1156,34 @@ def test_reconstruction_cache_skips_tiles_without_neurons(M):
     assert torch.equal(S3, fresh())
     S4 = dn._recon_cache()[0]
     assert torch.equal(S4, fresh())
+
+
+def test_footprint_floor_option(M, O):
+    """``ExponentialFP.footprint_floor`` (an extension, default 0: every non-zero value is listed): values below the floor
+    leave the neuron lists.  With a floor of 1e-12 the Gram data stay within 2e-6 of the exact-support result (the order
+    of the sums changes) and within the usual tolerance of the float64 oracle; the lists get shorter."""
+    from dnmf_amd import ops
+    torch.manual_seed(2)
+    sz, K, T = [160, 128, 1], 30, 4
+    pos = torch.rand(K, 3) * torch.tensor([160.0, 128.0, 0.0])
+    fp = M.ExponentialFP(torch.tensor(sz), K, T, positions=pos)
+    with torch.no_grad():
+        fp.beta += 1e-3 * torch.randn_like(fp.beta) * torch.tensor([1.0, 1e-2, 1e-2, 0, 1e-4, 1e-4, 0, 1e-4, 0, 0], device="cuda")[:, None, None]
+        fp.beta[:, 2] = torch.tensor([0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0], device="cuda")[:, None]
+    frames = torch.rand(T, fp.P, device="cuda")
+    G0, r0, _ = ops.warp_gram_rhs_lists(fp.packed_lists(), K, sz, fp.beta.detach(), None, frames)
+    box0 = fp.packed_lists()["boxfrac"]
+    fp.footprint_floor = 1e-12
+    ly = fp.packed_lists()
+    assert ly["boxfrac"] < 0.6 * box0
+    G1, r1, _ = ops.warp_gram_rhs_lists(ly, K, sz, fp.beta.detach(), None, frames)
+    for t in range(T):
+        assert float((G1[t] - G0[t]).abs().max()) <= 2e-6 * float(G0[t].abs().max())
+        assert float((r1[t] - r0[t]).abs().max()) <= 2e-6 * float(r0[t].abs().max())
+    A_t = ops.warp_gather(fp.A, fp.beta.detach(), list(range(T)), want_grid=False)[0].cpu().numpy()    # (T,K,X,Y,Z)
+    Gref, rref = O.gram_rhs(np.transpose(A_t.astype(np.float64), [2, 3, 4, 1, 0]),
+                            np.moveaxis(frames.cpu().numpy().reshape(T, *sz), 0, 3).astype(np.float64))
+    np.testing.assert_allclose(G1.cpu().numpy(), np.moveaxis(Gref, 2, 0), rtol=2e-5, atol=2e-5 * np.abs(Gref).max())
+    np.testing.assert_allclose(r1.cpu().numpy(), rref.T, rtol=2e-5, atol=2e-5 * np.abs(rref).max())
+    fp.footprint_floor = 0.0
+    assert fp.packed_lists()["boxfrac"] == box0
