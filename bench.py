@@ -620,102 +620,107 @@ def main():
         del res, dn, frames
         torch.cuda.empty_cache()
         extras = {}
-        # the smallest volume the reference itself can run has two slices (Demix/dNMF.py:55 divides by Z-1)
-        r2 = run_sweeps(args, [size, size, 2], K, T_loc, 5, 2, 0, 1, None)
-        tj = Traffic(ops.build_stamp())
-        key2 = f"{size}x{size}x2x{T_loc}_K{K}"
+        try:   # (after the timed region: an extra that fails must not take the headline line with it)
+            # the smallest volume the reference itself can run has two slices (Demix/dNMF.py:55 divides by Z-1)
+            r2 = run_sweeps(args, [size, size, 2], K, T_loc, 5, 2, 0, 1, None)
+            tj = Traffic(ops.build_stamp())
+            key2 = f"{size}x{size}x2x{T_loc}_K{K}"
 
-        def roofs_depth2(r):
-            P2 = 2 * P
-            out = []
-            k3 = r["evs"]("warp_gram_rhs_lists")
-            if k3:
-                ab = 4.0 * P2 * T_loc + 4.0 * P2 * K + 4.0 * T_loc * (K * K + K)
-                out.append(dict(hbm_roof("K3n at Z = 2: lists_tilemask_kernel + warp_gram_lists_kernel<2,...> (both passes)",
-                                         1e3 * sum(k3) / len(k3), ab, "frames 4PT + footprints 4PK + G, r 4T(K^2+K)",
-                                         tj.get(key2 + "_lists")), valu_issue=tj.get(key2 + "_lists_valu")))
-            out += other_kernels(r["evs"], P2, K, T_loc, tj, key2, ops.halo_voxels([size, size, 2]))
-            return out
+            def roofs_depth2(r):
+                P2 = 2 * P
+                out = []
+                k3 = r["evs"]("warp_gram_rhs_lists")
+                if k3:
+                    ab = 4.0 * P2 * T_loc + 4.0 * P2 * K + 4.0 * T_loc * (K * K + K)
+                    out.append(dict(hbm_roof("K3n at Z = 2: lists_tilemask_kernel + warp_gram_lists_kernel<2,...> (both passes)",
+                                             1e3 * sum(k3) / len(k3), ab, "frames 4PT + footprints 4PK + G, r 4T(K^2+K)",
+                                             tj.get(key2 + "_lists")), valu_issue=tj.get(key2 + "_lists_valu")))
+                out += other_kernels(r["evs"], P2, K, T_loc, tj, key2, ops.halo_voxels([size, size, 2]))
+                return out
 
-        extras["depth2"] = dict(short_line(r2, 5, roofs_depth2), workload=f"{size}x{size}x2x{T_loc}, K={K}: the 8-tap kernel variants")
-        del r2
-        torch.cuda.empty_cache()
-        # the footprint update the reference leaves commented out, wired in (K7 registration + K5 + K6)
-        r3 = run_sweeps(args, sz, K, T_loc, 3, 1, 0, 1, None, with_spatial=True)
-
-        def roofs_spatial(r):
-            out = []
-            if r["per_step_ms"].get("image_iwarp"):   # (several launches per sweep: the flag bytes of a launch are bounded)
-                out.append(hbm_roof("image_iwarp kernels (K7: nearest warped voxel of every lattice point), all launches of a sweep",
-                                    r["per_step_ms"]["image_iwarp"], 8.0 * P * T_loc, "frames read 4PT + registered frames written 4PT"))
-            for name in ("spatial_accum", "spatial_accum_lists"):
-                if r["per_step_ms"].get(name):
-                    out.append(hbm_roof(f"{name} (K5: A1 = Y_i C^T over the frames)", r["per_step_ms"][name],
-                                        4.0 * P * T_loc + 4.0 * K * T_loc + 4.0 * P * K,
-                                        "registered frames 4PT + traces 4KT read, A1 4PK written"))
-            return out
-
-        extras["with_spatial"] = dict(short_line(r3, 3, roofs_spatial), workload="the default sweep + update_footprints(live_spatial=True)")
-        del r3
-        torch.cuda.empty_cache()
-        # the same sweep from warps a few voxels off the identity (longer tile lists, K7 windows beyond one cell)
-        r3 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, beta_init="displaced")
-        extras["displaced_beta"] = dict(short_line(r3, 5), workload="the default sweep started from smooth warps a few voxels "
-                                        "off the identity (bench.py: displaced_beta) instead of the identity")
-        del r3
-        torch.cuda.empty_cache()
-        # what demo.py really drives: a stock DataLoader over a host video (PCIe-inclusive, host-bound)
-        dl = {}
-        for name, s2, K2, T2 in (("config2_256x256x1000_K50", 256, 50, 1000), ("config3_subset_512x512x400_K100", 512, 100, 400)):
-            r4 = run_sweeps(args, [s2, s2, 1], K2, T2, 2, 1, 0, 1, None, loader="dataloader")
-            dl[name] = short_line(r4, 2)
-            del r4
+            extras["depth2"] = dict(short_line(r2, 5, roofs_depth2), workload=f"{size}x{size}x2x{T_loc}, K={K}: the 8-tap kernel variants")
+            del r2
             torch.cuda.empty_cache()
-        r5 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, loader="dataset")
-        dl["simulated_video_dataset_512x512x4000_K100"] = dict(
-            short_line(r5, 5), note="the same stock DataLoaders over the library's SimulatedVideoDataset (host video, as in "
-                                    "demo.py): frames come from dataset.device_frames(), only the loaders' index batches "
-                                    "are drawn")
-        del r5
-        torch.cuda.empty_cache()
-        # footprint values below a floor left out of the neuron lists (dnmf_amd/Demix/dNMF.py: footprint_floor): the same
-        # fit, the same number of sweeps, compared with the exact-support fit
-        ff = {}
-        ref = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None)
-        C_ref, b_ref = ref["dn"].C.clone(), ref["dn"].fp.beta.detach().clone()
-        del ref
-        torch.cuda.empty_cache()
-        def deviation(r):
-            dC = (r["dn"].C - C_ref).abs()
-            return dict(max_trace_deviation_over_max_trace=float(dC.max() / C_ref.abs().max()),
-                        max_rel_trace_deviation=float((dC / C_ref.abs().clamp_min(1e-30)).max()),
-                        max_abs_beta_deviation=float((r["dn"].fp.beta.detach() - b_ref).abs().max()))
+            # the footprint update the reference leaves commented out, wired in (K7 registration + K5 + K6)
+            r3 = run_sweeps(args, sz, K, T_loc, 3, 1, 0, 1, None, with_spatial=True)
 
-        # the yardstick: the SAME exact-support fit with the Gram data from the dense kernel K3 (every product, MFMA, another
-        # order of the fp32 sums: a few units in the last place per entry).  The alternating fit amplifies such a difference
-        # from sweep to sweep, whatever its source.
-        gram0 = args.gram
-        args.gram = "dense"
-        try:
-            r6 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None)
-        finally:
-            args.gram = gram0
-        ff["yardstick_exact_support_other_summation_order"] = dict(deviation(r6), what="the same fit with the dense Gram kernel K3")
-        del r6
-        torch.cuda.empty_cache()
-        for floor in (1e-20, 1e-10):
-            r6 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, footprint_floor=floor)
-            ff[f"{floor:g}"] = dict(short_line(r6, 5), **deviation(r6), listed_neurons_per_voxel=r6["dn"].fp.packed_lists()["boxfrac"])
+            def roofs_spatial(r):
+                out = []
+                if r["per_step_ms"].get("image_iwarp"):   # (several launches per sweep: the flag bytes of a launch are bounded)
+                    out.append(hbm_roof("image_iwarp kernels (K7: nearest warped voxel of every lattice point), all launches of a sweep",
+                                        r["per_step_ms"]["image_iwarp"], 8.0 * P * T_loc, "frames read 4PT + registered frames written 4PT"))
+                for name in ("spatial_accum", "spatial_accum_lists"):
+                    if r["per_step_ms"].get(name):
+                        out.append(hbm_roof(f"{name} (K5: A1 = Y_i C^T over the frames)", r["per_step_ms"][name],
+                                            4.0 * P * T_loc + 4.0 * K * T_loc + 4.0 * P * K,
+                                            "registered frames 4PT + traces 4KT read, A1 4PK written"))
+                return out
+
+            extras["with_spatial"] = dict(short_line(r3, 3, roofs_spatial), workload="the default sweep + update_footprints(live_spatial=True)")
+            del r3
+            torch.cuda.empty_cache()
+            # the same sweep from warps a few voxels off the identity (longer tile lists, K7 windows beyond one cell)
+            r3 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, beta_init="displaced")
+            extras["displaced_beta"] = dict(short_line(r3, 5), workload="the default sweep started from smooth warps a few voxels "
+                                            "off the identity (bench.py: displaced_beta) instead of the identity")
+            del r3
+            torch.cuda.empty_cache()
+            # what demo.py really drives: a stock DataLoader over a host video (PCIe-inclusive, host-bound)
+            dl = {}
+            for name, s2, K2, T2 in (("config2_256x256x1000_K50", 256, 50, 1000), ("config3_subset_512x512x400_K100", 512, 100, 400)):
+                r4 = run_sweeps(args, [s2, s2, 1], K2, T2, 2, 1, 0, 1, None, loader="dataloader")
+                dl[name] = short_line(r4, 2)
+                del r4
+                torch.cuda.empty_cache()
+            r5 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, loader="dataset")
+            dl["simulated_video_dataset_512x512x4000_K100"] = dict(
+                short_line(r5, 5), note="the same stock DataLoaders over the library's SimulatedVideoDataset (host video, as in "
+                                        "demo.py): frames come from dataset.device_frames(), only the loaders' index batches "
+                                        "are drawn")
+            del r5
+            torch.cuda.empty_cache()
+            # footprint values below a floor left out of the neuron lists (dnmf_amd/Demix/dNMF.py: footprint_floor): the same
+            # fit, the same number of sweeps, compared with the exact-support fit
+            ff = {}
+            ref = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None)
+            C_ref, b_ref = ref["dn"].C.clone(), ref["dn"].fp.beta.detach().clone()
+            del ref
+            torch.cuda.empty_cache()
+            def deviation(r):
+                dC = (r["dn"].C - C_ref).abs()
+                return dict(max_trace_deviation_over_max_trace=float(dC.max() / C_ref.abs().max()),
+                            max_rel_trace_deviation=float((dC / C_ref.abs().clamp_min(1e-30)).max()),
+                            max_abs_beta_deviation=float((r["dn"].fp.beta.detach() - b_ref).abs().max()))
+
+            # the yardstick: the SAME exact-support fit with the Gram data from the dense kernel K3 (every product, MFMA, another
+            # order of the fp32 sums: a few units in the last place per entry).  The alternating fit amplifies such a difference
+            # from sweep to sweep, whatever its source.
+            gram0 = args.gram
+            args.gram = "dense"
+            try:
+                r6 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None)
+            finally:
+                args.gram = gram0
+            ff["yardstick_exact_support_other_summation_order"] = dict(deviation(r6), what="the same fit with the dense Gram kernel K3")
             del r6
             torch.cuda.empty_cache()
-        extras["footprint_floor"] = dict(ff, note="NOT the headline: the default keeps every non-zero footprint value (a Gaussian "
-                                         "footprint is a non-zero fp32 number out to 30 voxels).  Deviations are against the "
-                                         "exact-support fit after the same 7 sweeps: summation order, not lost terms")
-        del C_ref, b_ref
-        extras["position_initialiser"] = position_initialiser_extra(size)
-        extras["stock_dataloader"] = dict(dl, note="torch.utils.data.DataLoader(batch 4, shuffle, num_workers=0) over a host "
-                                                   "copy of the video, as demo.py:33-35; every sweep serves the video twice "
-                                                   "from the host (update_motion, update_footprints)")
+            for floor in (1e-20, 1e-10):
+                r6 = run_sweeps(args, sz, K, T_loc, 5, 2, 0, 1, None, footprint_floor=floor)
+                ff[f"{floor:g}"] = dict(short_line(r6, 5), **deviation(r6), listed_neurons_per_voxel=r6["dn"].fp.packed_lists()["boxfrac"])
+                del r6
+                torch.cuda.empty_cache()
+            extras["footprint_floor"] = dict(ff, note="NOT the headline: the default keeps every non-zero footprint value (a Gaussian "
+                                             "footprint is a non-zero fp32 number out to 30 voxels).  Deviations are against the "
+                                             "exact-support fit after the same 7 sweeps: summation order, not lost terms")
+            del C_ref, b_ref
+            extras["position_initialiser"] = position_initialiser_extra(size)
+            extras["stock_dataloader"] = dict(dl, note="torch.utils.data.DataLoader(batch 4, shuffle, num_workers=0) over a host "
+                                                       "copy of the video, as demo.py:33-35; every sweep serves the video twice "
+                                                       "from the host (update_motion, update_footprints)")
+        except Exception as err:   # noqa: BLE001
+            import traceback
+            extras["error"] = f"{type(err).__name__}: {err}"
+            traceback.print_exc(file=sys.stderr)
         line["extras"] = extras
     # N > 1: who took part.  One all-gather of (rank, device ordinal, PCI bus id) over the process group the sweeps ran
     # under: N distinct devices = N RCCL ranks, without NCCL_DEBUG.
