@@ -203,3 +203,27 @@ def test_neuropal_dataset_reads_mat_files(tmp_path):
     np.testing.assert_allclose(ds.positions[:, 2].numpy(), (pos[:, 2] - 1) / 10, rtol=1e-6)
     frame, idx = ds[3]
     assert idx == 3 and frame.min() >= 0 and frame.shape == (6, 5, 2)
+
+
+def test_patch_grid_and_workspaces_of_the_position_initialiser(lib):
+    """K8's host logic without a GPU: the patch grid equals the oracle's sliding_window_3d (reference
+    MotionCorrect.py:1190-1221) -- windows of strides + overlaps every `strides`, the last one flush with the end --, windows
+    that do not fit are refused, and the workspaces grow with the number of frames."""
+    from oracle import motion_oracle as MO
+    I3 = ctypes.c_int * 3
+    for sz, strides, overlaps in (((48, 40, 2), (16, 12, 1), (8, 8, 1)), ((512, 512, 2), (96, 96, 1), (32, 32, 1)),
+                                  ((40, 36, 5), (12, 12, 2), (8, 6, 1)), ((64, 64, 1), (24, 24, 1), (8, 8, 0))):
+        ref = MO.sliding_window_3d(sz, overlaps, strides)
+        dims = I3()
+        NP = lib.dnmf_register_patches_grid(*sz, I3(*strides), I3(*overlaps), dims, None)
+        assert NP == len(ref) and tuple(dims) == tuple(np.array(ref[-1][:3]) + 1)
+        starts = (ctypes.c_int * (3 * NP))()
+        assert lib.dnmf_register_patches_grid(*sz, I3(*strides), I3(*overlaps), dims, starts) == NP
+        np.testing.assert_array_equal(np.array(starts).reshape(NP, 3), np.array([g[3:6] for g in ref]))
+        w1 = lib.dnmf_register_patches_workspace(*sz, I3(*strides), I3(*overlaps), 1)
+        w8 = lib.dnmf_register_patches_workspace(*sz, I3(*strides), I3(*overlaps), 8)
+        assert 0 < w1 <= w8
+        assert 0 < lib.dnmf_rigid_correct_workspace(*sz, 1) <= lib.dnmf_rigid_correct_workspace(*sz, 8)
+    assert lib.dnmf_register_patches_grid(32, 32, 2, I3(24, 24, 1), I3(16, 16, 1), None, None) == 0      # 40 > 32: no window fits
+    assert lib.dnmf_register_patches_workspace(32, 32, 2, I3(24, 24, 1), I3(16, 16, 1), 4) == 0
+    assert lib.dnmf_rigid_correct_workspace(0, 4, 4, 1) == 0
